@@ -1,0 +1,252 @@
+/* include/rt_hip.h -- C ABI of librt_hip.so, the MI355X (gfx950) ray-tracing back end.
+ *
+ * This is the drop-in boundary for the hot path of Kupoman/raytracer: everything the reference's
+ * host code would bind to replace IAccel (raytracer/rt_iaccel.h:4-11) and
+ * RayTracer::processRays (raytracer/rt_raytracer.h:58) with HIP kernels.  Plain pointers and
+ * sizes only.  Every function returns 0 on success or a negative rt_hip_status; the message of
+ * the last failure on the calling thread is available from rt_hip_last_error().
+ *
+ * Pointer conventions: parameters named `d_*` are DEVICE pointers (HBM resident, used by callers
+ * that keep the G-buffer on the GPU); all other pointers are HOST pointers that are borrowed for
+ * the duration of the call (the reference borrows the rasterizer's transfer buffers the same
+ * way, rasterizer/ras_rasterizer.cpp:172-173,527-528).  Outputs returned through `const T**`
+ * point into context-owned pinned host memory and stay valid until the next call on the same
+ * context (the reference returns pointers into RayTracer members, rt_raytracer.cpp:536-539).
+ *
+ * A context is externally synchronised: one caller thread at a time (the reference's
+ * processRays is non-re-entrant, rt_raytracer.cpp:27-48).  Independent contexts are independent.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_hip_ctx rt_hip_ctx;
+
+enum rt_hip_status {
+	RT_HIP_OK = 0,
+	RT_HIP_ERR_ARG = -1,      /* bad argument (null pointer, negative count, unknown id) */
+	RT_HIP_ERR_HIP = -2,      /* a HIP runtime call failed; see rt_hip_last_error() */
+	RT_HIP_ERR_STATE = -3,    /* call order (e.g. trace before rt_hip_update) */
+	RT_HIP_ERR_LIMIT = -4     /* a documented limit was exceeded */
+};
+
+/* Byte-identical to the reference's struct Ray (data/data.h:34-42), which is both the ray and
+ * the hit record, and the GL vertex format of drawRayData (ras_rasterizer.cpp:586-589). */
+typedef struct rt_ray {
+	float origin[3];
+	float direction[3];
+	float position[3];
+	float normal[3];
+	float texcoord[2];
+	float pad[2];
+} rt_ray; /* 64 bytes */
+
+/* Field-for-field the reference's struct Material (data/data.h:18-26); `texture` is the
+ * Texture* slot, carried opaquely (textures are a "next" row). */
+typedef struct rt_material {
+	float diffuse_color[3];   /* 0..255 */
+	float specular_color[3];  /* 0..255 */
+	float shininess;
+	float reflectivity;
+	float alpha;              /* 1 - opacity (data/loader.cpp:104-105) */
+	float ior;
+	uint64_t texture;
+} rt_material; /* 48 bytes */
+
+/* The reference's struct Light (data/data.h:44-48). */
+typedef struct rt_light {
+	float position[3];
+	float color[3];
+	float energy;
+} rt_light; /* 28 bytes */
+
+/* The reference's ResultOffset = std::pair<Material*, int> (data/data.h:28) with the Material*
+ * replaced by the dense material id; `end` is the CUMULATIVE end offset into the result array
+ * (rt_raytracer.cpp:531-533). */
+typedef struct rt_result_offset {
+	uint32_t material;
+	int32_t end;
+} rt_result_offset;
+
+/* Per-ray hit, the reference's DACRayResult (rt_raytracer.cpp:38-46) without the ray copy. */
+typedef struct rt_hit {
+	uint32_t prim;            /* global triangle id in mesh-then-face order; 0xFFFFFFFF = miss */
+	float t;
+	float u;
+	float v;
+} rt_hit; /* 16 bytes */
+
+enum rt_hip_geometry { RT_HIP_TRIANGLES = 0, RT_HIP_SPHERES = 1 };
+enum rt_hip_accel { RT_HIP_ACCEL_AUTO = 0, RT_HIP_ACCEL_BRUTE = 1, RT_HIP_ACCEL_LBVH = 2 };
+
+/* Constants the reference hard-codes (file:line beside each). */
+typedef struct rt_hip_config {
+	int device;               /* HIP device ordinal */
+	int geometry;             /* rt_hip_geometry: AccelArray-like triangles or AccelSpheres */
+	int accel;                /* rt_hip_accel; AUTO = brute force below 512 triangles, else LBVH */
+	int use_model_mat;        /* 1: world space, vertices x model_mat (processRays, rt_raytracer.cpp:466-475)
+	                             0: object space (AccelArray::addMesh, rt_accel_array.cpp:17-32) */
+	float eps_det;            /* reject det <  eps_det.  FLT_EPSILON (rt_raytracer.cpp:18,336) or the
+	                             float equivalent of the double 1e-5 (rt_accel_array.cpp:10,94) */
+	float eps_t;              /* reject t   <  eps_t  (rt_raytracer.cpp:356 / rt_accel_array.cpp:114) */
+	float t_max;              /* accept t < t_max: +inf (rt_raytracer.cpp:451) or 1e6 (rt_accel_array.cpp:84) */
+	int bounces;              /* 2      rt_raytracer.cpp:52 */
+	int do_shadows;           /* 0      rt_raytracer.cpp:54 */
+	int use_photon_map;       /* 0      rt_raytracer.cpp:56 (photon_map == NULL) */
+	int photon_count;         /* 10000  rt_raytracer.cpp:57 */
+	int photon_estimate;      /* 100    rt_raytracer.cpp:58 */
+	float photon_radius;      /* 1.0    rt_raytracer.cpp:59 */
+	float photon_max_dist;    /* 12     rt_photon_map.cpp:92 */
+	float photon_absorb;      /* 0.6    rt_photon_map.cpp:45 */
+	uint64_t seed;            /* counter-RNG seed of the photon pass */
+	int profile;              /* 1: bracket the trace kernels with hipEvents (rt_hip_get_stats) */
+	int reserved;
+} rt_hip_config;
+
+/* Kernel-time accounting for bench.py (only filled when config.profile != 0). */
+typedef struct rt_hip_stats {
+	double trace_ms;          /* summed device time of the BVH / brute-force trace kernels */
+	int64_t trace_launches;
+	int64_t rays_closest;     /* closest-hit rays issued */
+	int64_t rays_any;         /* any-hit (shadow) rays issued */
+	double build_ms;          /* last rt_hip_update: soup + LBVH build */
+	int64_t num_tris;
+	int64_t num_nodes;
+	int32_t bvh_depth;
+	int32_t reserved;
+	double frame_ms;          /* summed device time of whole frames (render / process entries) */
+	int64_t frames;
+} rt_hip_stats;
+
+/* ---- life cycle --------------------------------------------------------------------------- */
+/* processRays semantics (world space, FLT_EPSILON, t_max = +inf, bounces 2, no shadows). */
+int rt_hip_default_config(rt_hip_config* cfg);
+/* AccelArray semantics (object space, double 1e-5 thresholds, t_max = 1e6). */
+int rt_hip_array_config(rt_hip_config* cfg);
+int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out);      /* RayTracer::RayTracer / AccelArray::AccelArray */
+int rt_hip_destroy(rt_hip_ctx* ctx);
+const char* rt_hip_last_error(void);
+int rt_hip_set_config(rt_hip_ctx* ctx, const rt_hip_config* cfg);   /* shading/photon fields only */
+
+/* ---- scene -------------------------------------------------------------------------------- */
+/* Scene::materials / Scene::lights (data/scene.h:8-10).  Material ids are indices into this table. */
+int rt_hip_set_materials(rt_hip_ctx* ctx, const rt_material* materials, int n);
+int rt_hip_set_lights(rt_hip_ctx* ctx, const rt_light* lights, int n);
+/* IAccel::addMesh / RayTracer::addMesh (rt_iaccel.h:7, rt_raytracer.cpp:69).  Geometry is copied.
+ * model_mat16 is column-major (Eigen default).  position3 is Mesh::position (the sphere centre
+ * for RT_HIP_SPHERES, rt_accel_spheres.cpp:27-31).  Returns the mesh id (>= 0). */
+int rt_hip_add_mesh(rt_hip_ctx* ctx, const float* verts, const float* normals, const float* texcoords,
+                    int nverts, const uint32_t* faces, int nfaces, const float* model_mat16,
+                    int material_id, const float* position3);
+/* AccelSpheres::addSphere (rt_accel_spheres.cpp:14-26); the colour comes from libc
+ * rand()%256 under srand(420) exactly as the reference draws it. */
+int rt_hip_add_sphere(rt_hip_ctx* ctx, float x, float y, float z, float radius);
+int rt_hip_set_model_mat(rt_hip_ctx* ctx, int mesh_id, const float* model_mat16);
+/* IAccel::update (rt_iaccel.h:8): rebuild the world-space triangle soup (rt_raytracer.cpp:457-503)
+ * and the LBVH on the GPU.  Must be called after the scene changes and before tracing. */
+int rt_hip_update(rt_hip_ctx* ctx);
+
+/* ---- IAccel batch entries ------------------------------------------------------------------ */
+/* IAccel::intersect for n rays (rt_iaccel.h:10; rt_accel_array.cpp:75-137 / rt_accel_spheres.cpp:58-104).
+ * rays[i].origin/direction are read; on a hit position/normal/texcoord are written, on a miss the
+ * ray is untouched.  hit_out[i] = 1/0; material_out[i] = material id (sphere index for spheres)
+ * or 0xFFFFFFFF; hits_out (optional) receives prim/t/u/v. */
+int rt_hip_intersect(rt_hip_ctx* ctx, rt_ray* rays, int n, uint8_t* hit_out, uint32_t* material_out,
+                     rt_hit* hits_out);
+/* IAccel::occlude for n rays (rt_iaccel.h:9; rt_accel_array.cpp:45-73: t is never tested;
+ * rt_accel_spheres.cpp:38-56: infinite line). */
+int rt_hip_occlude(rt_hip_ctx* ctx, const rt_ray* rays, int n, uint8_t* occluded_out);
+/* Diffuse colours of the sphere materials (the reference hands out Material* per sphere). */
+int rt_hip_sphere_colors(rt_hip_ctx* ctx, float* rgb_out, int max_spheres);
+
+/* ---- RayTracer::processRays (rt_raytracer.h:58, rt_raytracer.cpp:428-540) ------------------ */
+/* One reflection ray per G-buffer sample, closest hit, hit records grouped by material with
+ * cumulative end offsets; hits only; ascending input index inside a group.  Groups are ordered
+ * by ascending material id (the reference orders by Material* address, which no caller can
+ * rely on).  `camera` is unused by the reference (:447) and has no parameter here. */
+int rt_hip_process_gbuffer(rt_hip_ctx* ctx, const float* positions_xyz, const float* normals_xyz, int count,
+                           const rt_ray** results, const rt_result_offset** result_offsets,
+                           int* out_result_count, int* out_material_count);
+/* Per-input-ray hits of the last rt_hip_process_gbuffer (the reference exposes the same data as
+ * the global dac_results, rt_raytracer.cpp:48). */
+int rt_hip_last_hits(rt_hip_ctx* ctx, rt_hit* hits_out, float* directions_out, int count);
+/* Same, G-buffer samples already in HBM and records left in HBM (d_results: count x 64 B,
+ * d_offsets: num_materials entries).  Counts are returned on the host. */
+int rt_hip_process_gbuffer_device(rt_hip_ctx* ctx, const float* d_positions_xyz, const float* d_normals_xyz,
+                                  int count, rt_ray* d_results, rt_result_offset* d_offsets,
+                                  int* out_result_count, int* out_material_count);
+
+/* ---- raw batch tracing on device buffers --------------------------------------------------- */
+/* d_org / d_dir: n x 3 floats.  Closest hit with the context's eps / t_max. */
+int rt_hip_trace_closest_device(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, rt_hit* d_hits);
+/* Any hit with intersect's acceptance tests (shadow rays, rt_raytracer.cpp:110-118). */
+int rt_hip_trace_any_device(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occluded);
+
+/* ---- G-buffer hand-off (rasterizer -> tracer) ---------------------------------------------- */
+/* Rasterizer::getRayTraceData's selection (ras_rasterizer.cpp:509-536,556-561): keep texel i when
+ * (interlace <= 1 or i % interlace == phase) and alpha > 0; normals decoded as c*2-1.  Stable.
+ * nrm_rgba: n x 4, pos_rgb: n x 3 (the readback layout).  Outputs are n x 3; returns the count. */
+int rt_hip_gbuffer_select_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n,
+                                 int interlace, int phase, float* d_positions_out, float* d_normals_out,
+                                 int* d_index_out, int* out_count);
+/* Software G-buffer producer: primary rays with Camera::getScreenRays
+ * geometry (data/camera.cpp:19-44), closest hit, prepass_fs encodings (UNORM16 normal, FP16
+ * position; prepass_fs.cpp:11-13, ras_rasterizer.cpp:293,301); alpha = material id + 1, 0 = empty. */
+int rt_hip_render_gbuffer_device(rt_hip_ctx* ctx, float fov, int width, int height, float* d_nrm_rgba,
+                                 float* d_pos_rgb);
+
+/* ---- full frame: G-buffer in, RGBA8 out ---------------------------------------------------- */
+/* Gen-1 shade() (rt_raytracer.cpp:75-160) evaluated at every G-buffer texel with alpha > 0
+ * (material id = alpha - 1), secondary rays (shadow, reflection, refraction) traced on the GPU;
+ * RGBA8 written as renderScene does (rt_raytracer.cpp:175-185).  Frame semantics: DESIGN.md.
+ * Host entry: uploads with hipMemcpyAsync, downloads the image. */
+int rt_hip_render_frame(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float* gbuf_nrm_rgba, int width,
+                        int height, uint8_t* rgba_out);
+int rt_hip_render_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba,
+                               int width, int height, uint8_t* d_rgba_out);
+/* Multi-GPU tile split: shade only texels whose tile (tile x tile pixels, row-rotated round
+ * robin) belongs to `rank` of `nranks`; other texels of d_rgba_out are left untouched. */
+int rt_hip_render_tiles_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba,
+                               int width, int height, int tile, int rank, int nranks, uint8_t* d_rgba_out);
+/* Secondary rays issued by the last frame call (shadow + reflection + refraction). */
+int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx);
+
+/* ---- photon map (raytracer/rt_photon_map.h:13-16) ------------------------------------------ */
+/* PhotonMap::generate (rt_photon_map.cpp:86-124) for photon indices [first, first+count) of the
+ * global sequence lights x photons_per_light, with the counter RNG keyed by (seed, index) so the
+ * result does not depend on how indices are sharded.  Stored photons (9 floats: position,
+ * energy, direction) are appended to d_photons_out in index order; *out_stored = how many. */
+int rt_hip_photon_emit_device(rt_hip_ctx* ctx, int photons_per_light, int64_t first, int64_t count,
+                              float* d_photons_out, int64_t capacity, int64_t* out_stored);
+/* Install the (all-gathered) photon set and build the hashed grid (cell = radius). */
+int rt_hip_photon_set_device(rt_hip_ctx* ctx, const float* d_photons, int64_t n);
+int rt_hip_photon_set(rt_hip_ctx* ctx, const float* photons, int64_t n);
+/* PhotonMap::radiance_estimate (rt_photon_map.cpp:149-208) at npts points. */
+int rt_hip_radiance_estimate_device(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int npts,
+                                    int count, float radius, float* d_rgb_out);
+int rt_hip_radiance_estimate(rt_hip_ctx* ctx, const float* pos, const float* nrm, int npts, int count,
+                             float radius, float* rgb_out);
+
+/* ---- introspection ------------------------------------------------------------------------- */
+int rt_hip_get_stats(rt_hip_ctx* ctx, rt_hip_stats* out);
+int rt_hip_reset_stats(rt_hip_ctx* ctx);
+int rt_hip_sync(rt_hip_ctx* ctx);
+/* The hipStream_t all of the context's work is enqueued on (as an opaque pointer). */
+void* rt_hip_stream(rt_hip_ctx* ctx);
+/* Copies of the LBVH for validation and for the roofline's nodes/ray census:
+ * nodes: num_nodes x 16 floats (64 B each, layout in DESIGN.md); leaf_prims: num_tris ids. */
+int rt_hip_get_bvh(rt_hip_ctx* ctx, float* nodes_out, int64_t max_nodes, uint32_t* leaf_prims_out,
+                   int64_t max_tris);
+/* Per-ray traversal census on the device: nodes visited and triangles tested per ray. */
+int rt_hip_trace_census_device(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, int any_hit,
+                               uint32_t* d_nodes_visited, uint32_t* d_tris_tested);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

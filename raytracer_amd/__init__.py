@@ -1,0 +1,354 @@
+"""raytracer_amd -- MI355X-native ray-tracing back end for the G-buffer ray tracer.
+
+The product is `librt_hip.so` (hand-written HIP for gfx950 behind the C ABI of
+`include/rt_hip.h`).  This package is the thin Python host binding used by the tests and by
+bench.py; it holds no compute and no CPU fallback: if the shared library is missing or no GPU is
+visible, calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librt_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_u8_p = C.POINTER(C.c_uint8)
+c_u32_p = C.POINTER(C.c_uint32)
+c_int_p = C.POINTER(C.c_int)
+
+RAY_DTYPE = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("position", "<f4", 3),
+                      ("normal", "<f4", 3), ("texcoord", "<f4", 2), ("pad", "<f4", 2)])
+HIT_DTYPE = np.dtype([("prim", "<u4"), ("t", "<f4"), ("u", "<f4"), ("v", "<f4")])
+OFFSET_DTYPE = np.dtype([("material", "<u4"), ("end", "<i4")])
+MATERIAL_DTYPE = np.dtype([("diffuse_color", "<f4", 3), ("specular_color", "<f4", 3), ("shininess", "<f4"),
+                           ("reflectivity", "<f4"), ("alpha", "<f4"), ("ior", "<f4"), ("texture", "<u8")])
+LIGHT_DTYPE = np.dtype([("position", "<f4", 3), ("color", "<f4", 3), ("energy", "<f4")])
+assert RAY_DTYPE.itemsize == 64 and MATERIAL_DTYPE.itemsize == 48 and LIGHT_DTYPE.itemsize == 28
+
+MISS = 0xFFFFFFFF
+TRIANGLES, SPHERES = 0, 1
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("geometry", C.c_int), ("accel", C.c_int), ("use_model_mat", C.c_int),
+                ("eps_det", C.c_float), ("eps_t", C.c_float), ("t_max", C.c_float), ("bounces", C.c_int),
+                ("do_shadows", C.c_int), ("use_photon_map", C.c_int), ("photon_count", C.c_int),
+                ("photon_estimate", C.c_int), ("photon_radius", C.c_float), ("photon_max_dist", C.c_float),
+                ("photon_absorb", C.c_float), ("seed", C.c_uint64), ("profile", C.c_int), ("reserved", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("trace_ms", C.c_double), ("trace_launches", C.c_int64), ("rays_closest", C.c_int64),
+                ("rays_any", C.c_int64), ("build_ms", C.c_double), ("num_tris", C.c_int64), ("num_nodes", C.c_int64),
+                ("bvh_depth", C.c_int32), ("reserved", C.c_int32), ("frame_ms", C.c_double), ("frames", C.c_int64)]
+
+
+# every symbol include/rt_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "rt_hip_default_config", "rt_hip_array_config", "rt_hip_create", "rt_hip_destroy", "rt_hip_last_error",
+    "rt_hip_set_config", "rt_hip_set_materials", "rt_hip_set_lights", "rt_hip_add_mesh", "rt_hip_add_sphere",
+    "rt_hip_set_model_mat", "rt_hip_update", "rt_hip_intersect", "rt_hip_occlude", "rt_hip_sphere_colors",
+    "rt_hip_process_gbuffer", "rt_hip_last_hits", "rt_hip_process_gbuffer_device", "rt_hip_trace_closest_device",
+    "rt_hip_trace_any_device", "rt_hip_gbuffer_select_device", "rt_hip_render_gbuffer_device", "rt_hip_render_frame",
+    "rt_hip_render_frame_device", "rt_hip_render_tiles_device", "rt_hip_last_frame_rays", "rt_hip_photon_emit_device",
+    "rt_hip_photon_set_device", "rt_hip_photon_set", "rt_hip_radiance_estimate_device", "rt_hip_radiance_estimate",
+    "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
+    "rt_hip_trace_census_device",
+]
+
+
+def build(verbose: bool = False) -> str:
+    """Compile librt_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc"), "-j8"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen librt_hip.so.  Never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("librt_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                           "raytracer_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    L.rt_hip_last_error.restype = C.c_char_p
+    L.rt_hip_default_config.argtypes = [C.POINTER(Config)]
+    L.rt_hip_array_config.argtypes = [C.POINTER(Config)]
+    L.rt_hip_create.argtypes = [C.POINTER(Config), C.POINTER(P)]
+    L.rt_hip_destroy.argtypes = [P]
+    L.rt_hip_set_config.argtypes = [P, C.POINTER(Config)]
+    L.rt_hip_set_materials.argtypes = [P, P, C.c_int]
+    L.rt_hip_set_lights.argtypes = [P, P, C.c_int]
+    L.rt_hip_add_mesh.argtypes = [P, c_float_p, c_float_p, c_float_p, C.c_int, c_u32_p, C.c_int, c_float_p, C.c_int, c_float_p]
+    L.rt_hip_add_sphere.argtypes = [P, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.rt_hip_set_model_mat.argtypes = [P, C.c_int, c_float_p]
+    L.rt_hip_update.argtypes = [P]
+    L.rt_hip_intersect.argtypes = [P, P, C.c_int, c_u8_p, c_u32_p, P]
+    L.rt_hip_occlude.argtypes = [P, P, C.c_int, c_u8_p]
+    L.rt_hip_sphere_colors.argtypes = [P, c_float_p, C.c_int]
+    L.rt_hip_process_gbuffer.argtypes = [P, c_float_p, c_float_p, C.c_int, C.POINTER(P), C.POINTER(P), c_int_p, c_int_p]
+    L.rt_hip_last_hits.argtypes = [P, P, c_float_p, C.c_int]
+    L.rt_hip_process_gbuffer_device.argtypes = [P, P, P, C.c_int, P, P, c_int_p, c_int_p]
+    L.rt_hip_trace_closest_device.argtypes = [P, P, P, C.c_int, P]
+    L.rt_hip_trace_any_device.argtypes = [P, P, P, C.c_int, P]
+    L.rt_hip_trace_census_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
+    L.rt_hip_gbuffer_select_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, c_int_p]
+    L.rt_hip_render_gbuffer_device.argtypes = [P, C.c_float, C.c_int, C.c_int, P, P]
+    L.rt_hip_render_frame.argtypes = [P, c_float_p, c_float_p, C.c_int, C.c_int, c_u8_p]
+    L.rt_hip_render_frame_device.argtypes = [P, P, P, C.c_int, C.c_int, P]
+    L.rt_hip_render_tiles_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_last_frame_rays.argtypes = [P]
+    L.rt_hip_last_frame_rays.restype = C.c_int64
+    L.rt_hip_photon_emit_device.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, C.c_int64, C.POINTER(C.c_int64)]
+    L.rt_hip_photon_set_device.argtypes = [P, P, C.c_int64]
+    L.rt_hip_photon_set.argtypes = [P, c_float_p, C.c_int64]
+    L.rt_hip_radiance_estimate_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_float, P]
+    L.rt_hip_radiance_estimate.argtypes = [P, c_float_p, c_float_p, C.c_int, C.c_int, C.c_float, c_float_p]
+    L.rt_hip_get_stats.argtypes = [P, C.POINTER(Stats)]
+    L.rt_hip_reset_stats.argtypes = [P]
+    L.rt_hip_sync.argtypes = [P]
+    L.rt_hip_stream.argtypes = [P]
+    L.rt_hip_stream.restype = P
+    L.rt_hip_get_bvh.argtypes = [P, c_float_p, C.c_int64, c_u32_p, C.c_int64]
+    _lib = L
+    return L
+
+
+class RtHipError(RuntimeError):
+    pass
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=c_float_p):
+    return a.ctypes.data_as(t)
+
+
+def _dptr(t):
+    """Device pointer of a torch tensor (or a raw int address)."""
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class RtHip:
+    """Host mirror of the reference's tracer objects over the C ABI.
+
+    `semantics="raytracer"` behaves like RayTracer (world space, FLT_EPSILON, t_max = inf);
+    `semantics="array"` like AccelArray (object space, 1e-5 as double, t_max = 1e6);
+    `geometry=SPHERES` like AccelSpheres.
+    """
+
+    def __init__(self, scene=None, semantics="raytracer", geometry=TRIANGLES, accel=ACCEL_AUTO, device=0, profile=0,
+                 **cfg_overrides):
+        self.lib = load_library()
+        self.cfg = Config()
+        if semantics == "array":
+            self._ck(self.lib.rt_hip_array_config(C.byref(self.cfg)))
+        else:
+            self._ck(self.lib.rt_hip_default_config(C.byref(self.cfg)))
+        self.cfg.geometry = geometry
+        self.cfg.accel = accel
+        self.cfg.device = device
+        self.cfg.profile = profile
+        for k, v in cfg_overrides.items():
+            setattr(self.cfg, k, v)
+        self.h = C.c_void_p()
+        self._ck(self.lib.rt_hip_create(C.byref(self.cfg), C.byref(self.h)))
+        self.scene = None
+        if scene is not None:
+            self.load_scene(scene)
+
+    def _ck(self, status):
+        if status is not None and status < 0:
+            raise RtHipError("rt_hip status %d: %s" % (status, self.lib.rt_hip_last_error().decode()))
+        return status
+
+    def close(self):
+        if self.h:
+            self.lib.rt_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scene ----------------------------------------------------------------------------
+    def load_scene(self, scene, update=True):
+        self.scene = scene
+        mats = np.zeros(len(scene.materials), MATERIAL_DTYPE)
+        for i, m in enumerate(scene.materials):
+            mats[i] = (m.diffuse, m.specular, m.shininess, m.reflectivity, m.alpha, m.ior, 0)
+        self._ck(self.lib.rt_hip_set_materials(self.h, mats.ctypes.data_as(C.c_void_p), len(mats)))
+        lights = np.zeros(len(scene.lights), LIGHT_DTYPE)
+        for i, li in enumerate(scene.lights):
+            lights[i] = (li.position, li.color, li.energy)
+        self._ck(self.lib.rt_hip_set_lights(self.h, lights.ctypes.data_as(C.c_void_p), len(lights)))
+        for me in scene.meshes:
+            self._ck(self.lib.rt_hip_add_mesh(self.h, _p(me.verts), _p(me.normals), _p(me.texcoords), me.verts.shape[0],
+                                              _p(me.faces, c_u32_p), me.faces.shape[0], _p(me.model_colmajor()),
+                                              me.material, _p(_f(me.position))))
+        if update:
+            self.update()
+
+    def update(self):
+        self._ck(self.lib.rt_hip_update(self.h))
+
+    def set_config(self, **kw):
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        self._ck(self.lib.rt_hip_set_config(self.h, C.byref(self.cfg)))
+
+    # ---- IAccel ---------------------------------------------------------------------------
+    def intersect(self, rays6):
+        rays6 = _f(rays6)
+        n = rays6.shape[0]
+        rec = np.zeros(n, RAY_DTYPE)
+        rec["origin"] = rays6[:, :3]
+        rec["direction"] = rays6[:, 3:]
+        hit = np.zeros(n, np.uint8)
+        mat = np.zeros(n, np.uint32)
+        hits = np.zeros(n, HIT_DTYPE)
+        self._ck(self.lib.rt_hip_intersect(self.h, rec.ctypes.data_as(C.c_void_p), n, _p(hit, c_u8_p), _p(mat, c_u32_p),
+                                           hits.ctypes.data_as(C.c_void_p)))
+        return dict(hit=hit, records=rec, material=mat.astype(np.int64).astype(np.int32), hits=hits)
+
+    def occlude(self, rays6):
+        rays6 = _f(rays6)
+        n = rays6.shape[0]
+        rec = np.zeros(n, RAY_DTYPE)
+        rec["origin"] = rays6[:, :3]
+        rec["direction"] = rays6[:, 3:]
+        occ = np.zeros(n, np.uint8)
+        self._ck(self.lib.rt_hip_occlude(self.h, rec.ctypes.data_as(C.c_void_p), n, _p(occ, c_u8_p)))
+        return occ
+
+    def sphere_colors(self, n):
+        out = np.zeros((n, 3), np.float32)
+        got = self._ck(self.lib.rt_hip_sphere_colors(self.h, _p(out), n))
+        return out[:got]
+
+    # ---- processRays ----------------------------------------------------------------------
+    def process_rays(self, pos, nrm):
+        pos, nrm = _f(pos), _f(nrm)
+        n = pos.shape[0]
+        res_p, off_p = C.c_void_p(), C.c_void_p()
+        nres, nmat = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.rt_hip_process_gbuffer(self.h, _p(pos), _p(nrm), n, C.byref(res_p), C.byref(off_p), C.byref(nres),
+                                                 C.byref(nmat)))
+        rec = np.zeros(nres.value, RAY_DTYPE)
+        if nres.value:
+            C.memmove(rec.ctypes.data, res_p.value, nres.value * 64)
+        off = np.zeros(nmat.value, OFFSET_DTYPE)
+        if nmat.value:
+            C.memmove(off.ctypes.data, off_p.value, nmat.value * 8)
+        hits = np.zeros(n, HIT_DTYPE)
+        dirs = np.zeros((n, 3), np.float32)
+        if n:
+            self._ck(self.lib.rt_hip_last_hits(self.h, hits.ctypes.data_as(C.c_void_p), _p(dirs), n))
+        return dict(tidx=hits["prim"].copy(), t=hits["t"].copy(), u=hits["u"].copy(), v=hits["v"].copy(), dir=dirs,
+                    records=rec, offset_material=off["material"].astype(np.int32), offset_end=off["end"].copy())
+
+    # ---- device-pointer entries (torch tensors or raw addresses) -----------------------------
+    def trace_closest_device(self, d_org, d_dir, n, d_hits):
+        self._ck(self.lib.rt_hip_trace_closest_device(self.h, _dptr(d_org), _dptr(d_dir), n, _dptr(d_hits)))
+
+    def trace_any_device(self, d_org, d_dir, n, d_occ):
+        self._ck(self.lib.rt_hip_trace_any_device(self.h, _dptr(d_org), _dptr(d_dir), n, _dptr(d_occ)))
+
+    def trace_census_device(self, d_org, d_dir, n, any_hit, d_nv, d_nt):
+        self._ck(self.lib.rt_hip_trace_census_device(self.h, _dptr(d_org), _dptr(d_dir), n, int(any_hit), _dptr(d_nv), _dptr(d_nt)))
+
+    def process_gbuffer_device(self, d_pos, d_nrm, n, d_results, d_offsets):
+        nres, nmat = C.c_int(0), C.c_int(0)
+        self._ck(self.lib.rt_hip_process_gbuffer_device(self.h, _dptr(d_pos), _dptr(d_nrm), n, _dptr(d_results),
+                                                        _dptr(d_offsets), C.byref(nres), C.byref(nmat)))
+        return nres.value, nmat.value
+
+    def gbuffer_select_device(self, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_pos_out, d_nrm_out, d_index_out):
+        cnt = C.c_int(0)
+        self._ck(self.lib.rt_hip_gbuffer_select_device(self.h, _dptr(d_nrm_rgba), _dptr(d_pos_rgb), n, interlace, phase,
+                                                       _dptr(d_pos_out), _dptr(d_nrm_out), _dptr(d_index_out), C.byref(cnt)))
+        return cnt.value
+
+    def render_gbuffer_device(self, fov, w, h, d_nrm_rgba, d_pos_rgb):
+        self._ck(self.lib.rt_hip_render_gbuffer_device(self.h, fov, w, h, _dptr(d_nrm_rgba), _dptr(d_pos_rgb)))
+
+    def render_frame_device(self, d_pos_rgb, d_nrm_rgba, w, h, d_rgba):
+        self._ck(self.lib.rt_hip_render_frame_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, _dptr(d_rgba)))
+
+    def render_tiles_device(self, d_pos_rgb, d_nrm_rgba, w, h, tile, rank, nranks, d_rgba):
+        self._ck(self.lib.rt_hip_render_tiles_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, tile, rank, nranks,
+                                                     _dptr(d_rgba)))
+
+    def render_frame(self, pos_rgb, nrm_rgba, w, h):
+        pos_rgb, nrm_rgba = _f(pos_rgb), _f(nrm_rgba)
+        out = np.zeros((h * w, 4), np.uint8)
+        self._ck(self.lib.rt_hip_render_frame(self.h, _p(pos_rgb), _p(nrm_rgba), w, h, _p(out, c_u8_p)))
+        return out
+
+    def last_frame_rays(self):
+        return int(self.lib.rt_hip_last_frame_rays(self.h))
+
+    # ---- photons --------------------------------------------------------------------------
+    def photon_emit_device(self, per_light, first, count, d_out, capacity):
+        stored = C.c_int64(0)
+        self._ck(self.lib.rt_hip_photon_emit_device(self.h, per_light, first, count, _dptr(d_out), capacity, C.byref(stored)))
+        return stored.value
+
+    def photon_set_device(self, d_photons, n):
+        self._ck(self.lib.rt_hip_photon_set_device(self.h, _dptr(d_photons), n))
+
+    def photon_set(self, photons9):
+        photons9 = _f(photons9)
+        self._ck(self.lib.rt_hip_photon_set(self.h, _p(photons9), photons9.shape[0]))
+
+    def radiance_estimate(self, pos, nrm, count=100, radius=1.0):
+        pos, nrm = _f(pos), _f(nrm)
+        out = np.zeros_like(pos)
+        self._ck(self.lib.rt_hip_radiance_estimate(self.h, _p(pos), _p(nrm), pos.shape[0], count, radius, _p(out)))
+        return out
+
+    def radiance_estimate_device(self, d_pos, d_nrm, npts, count, radius, d_out):
+        self._ck(self.lib.rt_hip_radiance_estimate_device(self.h, _dptr(d_pos), _dptr(d_nrm), npts, count, radius, _dptr(d_out)))
+
+    # ---- introspection --------------------------------------------------------------------
+    def stats(self):
+        s = Stats()
+        self._ck(self.lib.rt_hip_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def reset_stats(self):
+        self._ck(self.lib.rt_hip_reset_stats(self.h))
+
+    def sync(self):
+        self._ck(self.lib.rt_hip_sync(self.h))
+
+    def stream(self):
+        return self.lib.rt_hip_stream(self.h)
+
+    def get_bvh(self):
+        st = self.stats()
+        nn, nt = int(st["num_nodes"]), int(st["num_tris"])
+        nodes = np.zeros((nn, 16), np.float32)
+        prims = np.zeros(nt, np.uint32)
+        self._ck(self.lib.rt_hip_get_bvh(self.h, _p(nodes), nn, _p(prims, c_u32_p), nt))
+        return nodes, prims

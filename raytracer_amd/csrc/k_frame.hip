@@ -1,0 +1,869 @@
+// raytracer_amd/csrc/k_frame.hip -- everything around the trace kernels on the frame path:
+//   * reflection-ray generation from G-buffer samples       rt_raytracer.cpp:444-455
+//   * hit-record construction and group-by-material          rt_raytracer.cpp:510-539
+//   * G-buffer select / decode                               ras_rasterizer.cpp:509-536,556-561
+//   * software G-buffer producer (primary rays)              data/camera.cpp:19-44, prepass_fs.cpp:11-13
+//   * Gen-1 shade() as a level-synchronous wavefront         rt_raytracer.cpp:75-160
+//     (shadow any-hit rays per (light, node), ballot-compacted reflection / refraction queues,
+//     bottom-up colour combine in the reference's nesting order so the image is reproducible)
+#include <hip/hip_fp16.h>
+
+#include "rt_ctx.h"
+#include "rt_trace_dev.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int TRACE_BLOCK = 128;
+inline int nblocks(int64_t n, int b) { return (int)((n + b - 1) / b); }
+
+// Resolved hit: what IAccel::intersect leaves in the Ray plus the material.
+struct HitInfo {
+	float pos[3];
+	int material;  // -1 = miss
+	float nrm[3];
+	float pad;
+};
+
+struct NodeGeo {   // 48 B
+	float V[3];
+	int parent;    // level 0: pixel index; deeper: index of the parent node in the previous level
+	float N[3];
+	int material;  // -1: inactive
+	float I[3];
+	int branch;    // 0 reflection child, 1 refraction child
+};
+struct NodeShade { // 48 B
+	float F[3];    // shadow * light
+	float pad0;
+	float refc[3]; // colour returned by the reflection child (0 if none)
+	float pad1;
+	float refrc[3];
+	float pad2;
+};
+
+// ---- ray generation ------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_reflect_raygen(const float* __restrict__ pos, const float* __restrict__ nrm,
+                                                          int n, float* __restrict__ org, float* __restrict__ dir)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	f3 P = ld3(pos + 3 * (size_t)i), N = ld3(nrm + 3 * (size_t)i);
+	// direction = P - 2 * P.dot(N) * N, normalised (rt_raytracer.cpp:445-448)
+	f3 d = P - N * (2.0f * dot3(P, N));
+	st3(dir + 3 * (size_t)i, normalized3(d));
+	st3(org + 3 * (size_t)i, P);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_split_rays(const rt_ray* __restrict__ rays, int n, float* __restrict__ org,
+                                                      float* __restrict__ dir)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const float* r = (const float*)(rays + i);
+	for (int k = 0; k < 3; ++k) { org[3 * (size_t)i + k] = r[k]; dir[3 * (size_t)i + k] = r[3 + k]; }
+}
+
+// ---- hit resolution --------------------------------------------------------------------------
+__device__ __forceinline__ void resolve_tri(const SceneView& sv, const Hit& h, HitInfo& hi, float* texcoord)
+{
+	if (h.prim == RT_MISS) { hi.material = -1; return; }
+	const TriPos tp = sv.tri_pos[h.prim];
+	const TriAttr ta = sv.tri_attr[h.prim];
+	f3 p = bary3(h.u, h.v, mk3(tp.p0.x, tp.p0.y, tp.p0.z), mk3(tp.p1.x, tp.p1.y, tp.p1.z), mk3(tp.p2.x, tp.p2.y, tp.p2.z));
+	f3 nn = bary3(h.u, h.v, ld3(ta.n0), ld3(ta.n1), ld3(ta.n2));
+	nn = normalized3(nn);
+	st3(hi.pos, p);
+	st3(hi.nrm, nn);
+	hi.material = __float_as_int(tp.p0.w);
+	if (texcoord) {
+		float w = (1.0f - h.u - h.v);
+		texcoord[0] = (w * ta.t0[0] + h.u * ta.t1[0]) + h.v * ta.t2[0];
+		texcoord[1] = (w * ta.t0[1] + h.u * ta.t1[1]) + h.v * ta.t2[1];
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_resolve(SceneView sv, const Hit* __restrict__ hits, int n,
+                                                   HitInfo* __restrict__ out)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	HitInfo hi;
+	hi.pad = 0;
+	resolve_tri(sv, hits[i], hi, nullptr);
+	out[i] = hi;
+}
+
+// IAccel::intersect's write-back: hit -> position/normal/texcoord, miss -> untouched.
+__global__ __launch_bounds__(BLOCK) void k_fill_records(SceneView sv, const Hit* __restrict__ hits, int n,
+                                                        rt_ray* __restrict__ rays, uint8_t* __restrict__ flag,
+                                                        uint32_t* __restrict__ material)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	HitInfo hi;
+	float tc[2];
+	resolve_tri(sv, hits[i], hi, tc);
+	bool hit = hi.material >= 0;
+	flag[i] = hit ? 1 : 0;
+	material[i] = hit ? (uint32_t)hi.material : RT_MISS;
+	if (hit) {
+		float* r = (float*)(rays + i);
+		for (int k = 0; k < 3; ++k) { r[6 + k] = hi.pos[k]; r[9 + k] = hi.nrm[k]; }
+		r[12] = tc[0]; r[13] = tc[1];
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fill_sphere_records(const int* __restrict__ index,
+                                                               const float* __restrict__ pos,
+                                                               const float* __restrict__ nrm, int n,
+                                                               rt_ray* __restrict__ rays, uint8_t* __restrict__ flag,
+                                                               uint32_t* __restrict__ material)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	bool hit = index[i] >= 0;
+	flag[i] = hit ? 1 : 0;
+	material[i] = hit ? (uint32_t)index[i] : RT_MISS;
+	if (hit) {
+		float* r = (float*)(rays + i);
+		for (int k = 0; k < 3; ++k) { r[6 + k] = pos[3 * (size_t)i + k]; r[9 + k] = nrm[3 * (size_t)i + k]; }
+	}
+}
+
+// ---- group by material -----------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_material_digit(SceneView sv, const Hit* __restrict__ hits, int n, int shift,
+                                                          uint32_t* __restrict__ digit)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	uint32_t p = hits[i].prim;
+	uint32_t key = (p == RT_MISS) ? 0xFFFFu : (uint32_t)__float_as_int(sv.tri_pos[p].p0.w);
+	digit[i] = (key >> shift) & 255u;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_iota(uint32_t* p, int n)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n) p[i] = (uint32_t)i;
+}
+
+// perm_out[dest[i]] = perm_in[i]; digits for the next pass are gathered through the permutation
+__global__ __launch_bounds__(BLOCK) void k_apply_dest(const uint32_t* __restrict__ perm_in,
+                                                      const uint32_t* __restrict__ dest, int n,
+                                                      uint32_t* __restrict__ perm_out)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i < n) perm_out[dest[i]] = perm_in[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_material_digit_perm(SceneView sv, const Hit* __restrict__ hits,
+                                                               const uint32_t* __restrict__ perm, int n, int shift,
+                                                               uint32_t* __restrict__ digit)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	uint32_t p = hits[perm[i]].prim;
+	uint32_t key = (p == RT_MISS) ? 0xFFFFu : (uint32_t)__float_as_int(sv.tri_pos[p].p0.w);
+	digit[i] = (key >> shift) & 255u;
+}
+
+// records[slot] for slot < nres: the ray that landed in slot `slot` is perm[slot]
+__global__ __launch_bounds__(BLOCK) void k_emit_records(SceneView sv, const float* __restrict__ org,
+                                                        const float* __restrict__ dir, const Hit* __restrict__ hits,
+                                                        const uint32_t* __restrict__ perm, int nres,
+                                                        rt_ray* __restrict__ records)
+{
+	int s = blockIdx.x * BLOCK + threadIdx.x;
+	if (s >= nres) return;
+	uint32_t i = perm[s];
+	HitInfo hi;
+	float tc[2];
+	resolve_tri(sv, hits[i], hi, tc);
+	float* r = (float*)(records + s);
+	for (int k = 0; k < 3; ++k) {
+		r[k] = org[3 * (size_t)i + k];
+		r[3 + k] = dir[3 * (size_t)i + k];
+		r[6 + k] = hi.pos[k];
+		r[9 + k] = hi.nrm[k];
+	}
+	r[12] = tc[0]; r[13] = tc[1]; r[14] = 0.0f; r[15] = 0.0f;
+}
+
+// ---- G-buffer select -------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_select_digit(const float* __restrict__ nrm_rgba, int n, int interlace,
+                                                        int phase, uint32_t* __restrict__ digit)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	bool keep = nrm_rgba[4 * (size_t)i + 3] > 0.0f;
+	if (interlace > 1 && (i % interlace) != phase) keep = false;
+	digit[i] = keep ? 0u : 1u;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_select_scatter(const float* __restrict__ nrm_rgba,
+                                                          const float* __restrict__ pos_rgb,
+                                                          const uint32_t* __restrict__ digit,
+                                                          const uint32_t* __restrict__ dest, int n,
+                                                          float* __restrict__ pos_out, float* __restrict__ nrm_out,
+                                                          int* __restrict__ index_out)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n || digit[i] != 0u) return;
+	uint32_t d = dest[i];
+	for (int k = 0; k < 3; ++k) {
+		// (*normals)[i][k] = buffer * 2.0 - 1.0 in double, stored to float (ras_rasterizer.cpp:533-535)
+		nrm_out[3 * (size_t)d + k] = (float)((double)nrm_rgba[4 * (size_t)i + k] * 2.0 - 1.0);
+		pos_out[3 * (size_t)d + k] = pos_rgb[3 * (size_t)i + k];
+	}
+	if (index_out) index_out[d] = i;
+}
+
+// ---- software G-buffer (primary rays) -----------------------------------------------------------
+__device__ __forceinline__ float unorm16(float c)
+{
+	c = fminf(fmaxf(c, 0.0f), 1.0f);
+	return rintf(c * 65535.0f) / 65535.0f;
+}
+__device__ __forceinline__ float half_round(float f) { return __half2float(__float2half_rn(f)); }
+
+__global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, float tanfov, int w, int h,
+                                                                 float* __restrict__ nrm_rgba,
+                                                                 float* __restrict__ pos_rgb)
+{
+	extern __shared__ __attribute__((aligned(16))) int smem[];
+	int i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+	if (i >= w * h) return;
+	int x = i % w, y = i / w;
+	float aspect = float(w) / h;
+	float dirX = (float)(2 * ((x + 0.5) / w) - 1);
+	float dirY = (float)(2 * ((y + 0.5) / h) - 1);
+	dirX *= aspect;
+	f3 D = mk3(dirX * tanfov, dirY * tanfov, -1.0f);
+	f3 O = mk3(0, 0, 0);
+	float alpha = 0.0f;
+	f3 P = mk3(0, 0, 0), N = mk3(0, 0, 1);
+	if (sv.num_spheres > 0 && sv.num_tris == 0) {
+		// nearest sphere along the TRUE ray (the G-buffer producer stands in for the rasterizer,
+		// it does not inherit AccelSpheres::intersect's origin quirk)
+		float bestd = __builtin_inff();
+		f3 Dn = normalized3(D);
+		for (int k = 0; k < sv.num_spheres; ++k) {
+			f3 X, Nn;
+			if (sphere_test_ref(sv.spheres[k], O, Dn, X, Nn)) {
+				float d2 = dot3(X, X);
+				if (d2 < bestd) { bestd = d2; P = X; N = Nn; alpha = (float)(sv.num_materials - sv.num_spheres + k + 1); }
+			}
+		}
+	} else {
+		Hit best;
+		scene_trace<false>(sv, O, D, best, smem + threadIdx.x, TRACE_BLOCK);
+		if (best.prim != RT_MISS) {
+			HitInfo hi;
+			resolve_tri(sv, best, hi, nullptr);
+			P = ld3(hi.pos); N = ld3(hi.nrm);
+			alpha = (float)(hi.material + 1);
+		}
+	}
+	f3 nn = normalized3(N);
+	nrm_rgba[4 * (size_t)i + 0] = unorm16(nn.x * 0.5f + 0.5f);
+	nrm_rgba[4 * (size_t)i + 1] = unorm16(nn.y * 0.5f + 0.5f);
+	nrm_rgba[4 * (size_t)i + 2] = unorm16(nn.z * 0.5f + 0.5f);
+	nrm_rgba[4 * (size_t)i + 3] = alpha;
+	pos_rgb[3 * (size_t)i + 0] = half_round(P.x);
+	pos_rgb[3 * (size_t)i + 1] = half_round(P.y);
+	pos_rgb[3 * (size_t)i + 2] = half_round(P.z);
+}
+
+// ---- Gen-1 shade() wavefront ---------------------------------------------------------------------
+__device__ __forceinline__ bool tile_is_mine(int pixel, int w, int tile, int rank, int nranks)
+{
+	if (nranks <= 1) return true;
+	int x = pixel % w, y = pixel / w;
+	int tx = x / tile, ty = y / tile;
+	int tiles_x = (w + tile - 1) / tile;
+	(void)tiles_x;
+	// round robin along a row, rotated by the row index to decorrelate columns
+	return ((tx + ty) % nranks) == rank;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_init_nodes(const float* __restrict__ pos_rgb,
+                                                      const float* __restrict__ nrm_rgba, int w, int h, int tile,
+                                                      int rank, int nranks, int num_materials,
+                                                      NodeGeo* __restrict__ geo)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= w * h) return;
+	NodeGeo g;
+	float a = nrm_rgba[4 * (size_t)i + 3];
+	int mat = (a > 0.0f) ? ((int)a - 1) : -1;
+	if (mat >= num_materials) mat = -1;
+	if (!tile_is_mine(i, w, tile, rank, nranks)) mat = -2;  // -2: not this rank's texel, leave the pixel alone
+	f3 P = ld3(pos_rgb + 3 * (size_t)i);
+	f3 N;
+	// decode as getRayTraceData does (c*2-1 in double, not renormalised)
+	N.x = (float)((double)nrm_rgba[4 * (size_t)i + 0] * 2.0 - 1.0);
+	N.y = (float)((double)nrm_rgba[4 * (size_t)i + 1] * 2.0 - 1.0);
+	N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
+	st3(g.V, P); st3(g.N, N);
+	st3(g.I, mat >= 0 ? normalized3(P) : mk3(0, 0, 0));
+	g.parent = i; g.material = mat; g.branch = 0;
+	geo[i] = g;
+}
+
+// Shadow rays: one lane per (light, node); lanes of a wave share the light, so the rays of a
+// wave converge on one point.  occl[node] gets bit `light` when the ray is blocked.
+__global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const NodeGeo* __restrict__ geo, int n,
+                                                        unsigned int* __restrict__ occl)
+{
+	extern __shared__ __attribute__((aligned(16))) int smem[];
+	int64_t idx = (int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
+	if (idx >= (int64_t)n * sv.num_lights) return;
+	int light = (int)(idx / n), i = (int)(idx % n);
+	const NodeGeo g = geo[i];
+	if (g.material < 0) return;
+	f3 V = ld3(g.V), N = ld3(g.N);
+	f3 L = ld3(sv.lights[light].position) - V;
+	f3 O = V + N * 0.1f;  // bias = 0.1 (rt_raytracer.cpp:79,112)
+	bool blocked;
+	if (sv.num_spheres > 0 && sv.num_tris == 0) {
+		blocked = false;
+		f3 X, Nn;
+		for (int k = 0; k < sv.num_spheres; ++k)
+			if (sphere_test_ref(sv.spheres[k], L, L, X, Nn)) { blocked = true; break; }
+	} else {
+		Hit best;
+		blocked = scene_trace<true>(sv, O, L, best, smem + threadIdx.x, TRACE_BLOCK);
+	}
+	// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116)
+	if (blocked && 0.0f < norm3(L)) atomicOr(&occl[i], 1u << light);
+}
+
+// Per node: lambert / shadow -> F, and the reflection ray if this level may recurse.
+__global__ __launch_bounds__(BLOCK) void k_light_spawn_reflect(SceneView sv, const NodeGeo* __restrict__ geo,
+                                                               NodeShade* __restrict__ shade, int n,
+                                                               const unsigned int* __restrict__ occl,
+                                                               const float* __restrict__ photon_rgb, int do_shadows,
+                                                               int recurse, int* __restrict__ gate,
+                                                               float* __restrict__ q_org, float* __restrict__ q_dir,
+                                                               int* __restrict__ q_parent, int* __restrict__ q_count)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	bool emit = false;
+	f3 V = mk3(0, 0, 0), R = mk3(0, 0, 0);
+	if (i < n) {
+		const NodeGeo g = geo[i];
+		NodeShade s;
+		s.pad0 = s.pad1 = s.pad2 = 0;
+		st3(s.refc, mk3(0, 0, 0)); st3(s.refrc, mk3(0, 0, 0));
+		if (g.material >= 0) {
+			V = ld3(g.V);
+			f3 N = ld3(g.N), I = ld3(g.I);
+			const MaterialRec m = sv.materials[g.material];
+			if (photon_rgb) {
+				st3(s.F, ld3(photon_rgb + 3 * (size_t)i));  // shadow == 1
+			} else {
+				float lambert = 0.0f, shadow = 1.0f;
+				unsigned int oc = (do_shadows && occl) ? occl[i] : 0u;
+				for (int l = 0; l < sv.num_lights; ++l) {
+					f3 L = ld3(sv.lights[l].position) - V;
+					lambert += dot3(N, normalized3(L));
+					lambert = fminf(fmaxf(lambert, 0.0f), 1.0f);
+					if ((oc >> l) & 1u) shadow = (float)fmax((double)shadow - 0.4, 0.0);
+				}
+				float f = shadow * lambert;
+				st3(s.F, mk3(f, f, f));
+			}
+			gate[i] = g.material;
+			if (recurse && m.reflectivity > 0.0f) {
+				R = I - N * (2.0f * dot3(I, N));
+				emit = true;
+			}
+		} else {
+			st3(s.F, mk3(0, 0, 0));
+			gate[i] = -1;
+		}
+		shade[i] = s;
+	}
+	// wave-level compaction: one atomic per wave
+	uint64_t m = __ballot(emit);
+	if (m) {
+		int lane = lane_id();
+		int base = 0;
+		if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(q_count, (int)__popcll(m));
+		base = __shfl(base, (int)__builtin_ctzll(m));
+		if (emit) {
+			int s = base + (int)__popcll(m & lanemask_lt());
+			st3(q_org + 3 * (size_t)s, V);
+			st3(q_dir + 3 * (size_t)s, R);
+			q_parent[s] = i;
+		}
+	}
+}
+
+// Refraction spawn: gated by the (possibly overwritten, quirk Q9) material.
+__global__ __launch_bounds__(BLOCK) void k_spawn_refract(SceneView sv, const NodeGeo* __restrict__ geo, int n,
+                                                         const int* __restrict__ gate, float* __restrict__ q_org,
+                                                         float* __restrict__ q_dir, int* __restrict__ q_parent,
+                                                         int* __restrict__ q_count)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	bool emit = false;
+	f3 V = mk3(0, 0, 0), T = mk3(0, 0, 0);
+	if (i < n) {
+		int gm = gate[i];
+		if (gm >= 0) {
+			const MaterialRec m = sv.materials[gm];
+			if (m.alpha > 0.1f) {
+				const NodeGeo g = geo[i];
+				V = ld3(g.V);
+				f3 N = ld3(g.N), I = ld3(g.I);
+				float IoR = m.ior;
+				float idn = dot3(I, N);
+				T = div3(I - N * idn, IoR);
+				float arg = 1.0f - ((1.0f - idn * idn)) / IoR * IoR;  // (x / IoR) * IoR, the reference's precedence
+				float sq = rt_sqrtf(arg);
+				T = T - N * sq;
+				emit = true;
+			}
+		}
+	}
+	uint64_t m = __ballot(emit);
+	if (m) {
+		int lane = lane_id();
+		int base = 0;
+		if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(q_count, (int)__popcll(m));
+		base = __shfl(base, (int)__builtin_ctzll(m));
+		if (emit) {
+			int s = base + (int)__popcll(m & lanemask_lt());
+			st3(q_org + 3 * (size_t)s, V);
+			st3(q_dir + 3 * (size_t)s, T);
+			q_parent[s] = i;
+		}
+	}
+}
+
+// Sphere closest for the queue (AccelSpheres::intersect semantics: Ro = direction, first in list).
+__global__ __launch_bounds__(BLOCK) void k_queue_sphere_hits(SceneView sv, const float* __restrict__ q_dir, int nq,
+                                                             HitInfo* __restrict__ out)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= nq) return;
+	f3 Rd = ld3(q_dir + 3 * (size_t)i);
+	HitInfo hi;
+	hi.material = -1; hi.pad = 0;
+	f3 X, N;
+	for (int k = 0; k < sv.num_spheres; ++k) {
+		if (sphere_test_ref(sv.spheres[k], Rd, Rd, X, N)) {
+			st3(hi.pos, X); st3(hi.nrm, N);
+			hi.material = sv.num_materials - sv.num_spheres + k;  // sphere materials sit at the table's end
+			break;
+		}
+	}
+	out[i] = hi;
+}
+
+// Turn the resolved hits of a queue into child nodes of the next level.
+__global__ __launch_bounds__(BLOCK) void k_make_children(const HitInfo* __restrict__ hi, const float* __restrict__ q_dir,
+                                                         const int* __restrict__ q_parent, int nq, int branch,
+                                                         int* __restrict__ gate, NodeGeo* __restrict__ child_geo,
+                                                         int* __restrict__ child_count)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	bool hit = false;
+	HitInfo h;
+	if (i < nq) {
+		h = hi[i];
+		hit = h.material >= 0;
+		if (hit && branch == 0) gate[q_parent[i]] = h.material;  // Q9: reflection hit overwrites `material`
+	}
+	uint64_t m = __ballot(hit);
+	if (m) {
+		int lane = lane_id();
+		int base = 0;
+		if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(child_count, (int)__popcll(m));
+		base = __shfl(base, (int)__builtin_ctzll(m));
+		if (hit) {
+			int s = base + (int)__popcll(m & lanemask_lt());
+			NodeGeo g;
+			for (int k = 0; k < 3; ++k) { g.V[k] = h.pos[k]; g.N[k] = h.nrm[k]; g.I[k] = q_dir[3 * (size_t)i + k]; }
+			g.parent = q_parent[i];
+			g.material = h.material;
+			g.branch = branch;
+			child_geo[s] = g;
+		}
+	}
+}
+
+// Bottom-up combine of one level: color = (shadow*light) * ((kd*diff + ref*refc) + alpha*refrc)
+// (rt_raytracer.cpp:158).  Level 0 writes RGBA8 as renderScene does (rt_raytracer.cpp:175-185).
+__global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* __restrict__ geo,
+                                                   const NodeShade* __restrict__ shade, int n, int level,
+                                                   NodeShade* __restrict__ parent_shade, uint8_t* __restrict__ rgba,
+                                                   float* __restrict__ rgb_float)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const NodeGeo g = geo[i];
+	if (g.material == -2) return;
+	f3 col = mk3(0, 0, 0);
+	if (g.material >= 0) {
+		const MaterialRec m = sv.materials[g.material];
+		const NodeShade s = shade[i];
+		float ref = m.reflectivity, alpha = m.alpha;
+		float kd = (float)(1.0 - (double)ref - (double)alpha);
+		f3 mix = (ld3(m.diffuse) * kd + ld3(s.refc) * ref) + ld3(s.refrc) * alpha;
+		col = mk3(s.F[0] * mix.x, s.F[1] * mix.y, s.F[2] * mix.z);
+	}
+	if (level > 0) {
+		float* dst = g.branch == 0 ? parent_shade[g.parent].refc : parent_shade[g.parent].refrc;
+		st3(dst, col);
+	} else {
+		uint8_t* px = rgba + 4 * (size_t)g.parent;
+		if (g.material >= 0) {
+			px[0] = (uint8_t)min((int)col.x, 255);
+			px[1] = (uint8_t)min((int)col.y, 255);
+			px[2] = (uint8_t)min((int)col.z, 255);
+			px[3] = 255;
+		} else {
+			px[0] = px[1] = px[2] = px[3] = 0;
+		}
+		if (rgb_float) st3(rgb_float + 3 * (size_t)g.parent, col);
+	}
+}
+
+__global__ __launch_bounds__(BLOCK) void k_node_points(const NodeGeo* __restrict__ geo, int n, float* __restrict__ pos,
+                                                       float* __restrict__ nrm)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	for (int k = 0; k < 3; ++k) { pos[3 * (size_t)i + k] = geo[i].V[k]; nrm[3 * (size_t)i + k] = geo[i].N[k]; }
+}
+
+}  // namespace
+
+// ================================================================================================
+int rt_launch_split_rays(rt_hip_ctx* ctx, const rt_ray* d_rays, int n, float* d_org, float* d_dir)
+{
+	if (n <= 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_split_rays, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, d_rays, n, d_org, d_dir);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+int rt_launch_reflect_raygen(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int n, float* d_org,
+                             float* d_dir)
+{
+	if (n <= 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_reflect_raygen, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, d_pos, d_nrm, n, d_org, d_dir);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+int rt_launch_fill_records(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, const Hit* d_hits, int n,
+                           rt_ray* d_rays_inout, uint8_t* d_hit_flag, uint32_t* d_material)
+{
+	(void)d_org; (void)d_dir;
+	if (n <= 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_fill_records, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, rt_scene_view(ctx), d_hits, n,
+	                   d_rays_inout, d_hit_flag, d_material);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+int rt_fill_sphere_records(rt_hip_ctx* ctx, const int* d_index, const float* d_pos, const float* d_nrm, int n,
+                           rt_ray* d_rays, uint8_t* d_flag, uint32_t* d_material)
+{
+	if (n <= 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_fill_sphere_records, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, d_index, d_pos, d_nrm,
+	                   n, d_rays, d_flag, d_material);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+// Stable group-by-material of the hits (misses dropped): one 256-way multisplit per key byte.
+int rt_group_by_material(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, const Hit* d_hits, int n,
+                         rt_ray* d_records, rt_result_offset* d_offsets, int* out_results, int* out_groups)
+{
+	*out_results = 0;
+	*out_groups = 0;
+	if (n <= 0) return RT_HIP_OK;
+	hipStream_t st = ctx->stream;
+	SceneView sv = rt_scene_view(ctx);
+	const int nmat = (int)ctx->materials.size();
+	if (nmat >= 0xFFFF) { rt_set_error("more than 65534 materials"); return RT_HIP_ERR_LIMIT; }
+	RT_CHECK(ctx->d_keys.reserve((size_t)n * 4));
+	RT_CHECK(ctx->d_rank.reserve((size_t)n * 4));
+	RT_CHECK(ctx->d_in_a.reserve((size_t)n * 4));
+	RT_CHECK(ctx->d_in_b.reserve((size_t)n * 4));
+	RT_CHECK(ctx->d_counts.reserve(2 * 256 * 4));
+	uint32_t* digit = ctx->d_keys.as<uint32_t>();
+	uint32_t* dest = ctx->d_rank.as<uint32_t>();
+	uint32_t* perm_a = ctx->d_in_a.as<uint32_t>();
+	uint32_t* perm_b = ctx->d_in_b.as<uint32_t>();
+	uint32_t* totals = ctx->d_counts.as<uint32_t>();
+	const int g = nblocks(n, BLOCK);
+	const bool two_pass = nmat >= 255;
+	// pass 1: low byte (misses carry 0xFF / 0xFFFF and sort last)
+	hipLaunchKernelGGL(k_material_digit, dim3(g), dim3(BLOCK), 0, st, sv, d_hits, n, 0, digit);
+	RT_CHECK(rt_multisplit256(ctx, digit, n, dest, totals));
+	hipLaunchKernelGGL(k_iota, dim3(g), dim3(BLOCK), 0, st, perm_b, n);
+	hipLaunchKernelGGL(k_apply_dest, dim3(g), dim3(BLOCK), 0, st, perm_b, dest, n, perm_a);
+	uint32_t* perm = perm_a;
+	std::vector<uint32_t> h_lo(256), h_hi(256);
+	RT_HIP_CHECK(hipMemcpyAsync(h_lo.data(), totals, 256 * 4, hipMemcpyDeviceToHost, st));
+	if (two_pass) {
+		hipLaunchKernelGGL(k_material_digit_perm, dim3(g), dim3(BLOCK), 0, st, sv, d_hits, perm_a, n, 8, digit);
+		RT_CHECK(rt_multisplit256(ctx, digit, n, dest, totals + 256));
+		hipLaunchKernelGGL(k_apply_dest, dim3(g), dim3(BLOCK), 0, st, perm_a, dest, n, perm_b);
+		perm = perm_b;
+		RT_HIP_CHECK(hipMemcpyAsync(h_hi.data(), totals + 256, 256 * 4, hipMemcpyDeviceToHost, st));
+	}
+	RT_HIP_CHECK(hipGetLastError());
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	int misses = two_pass ? (int)h_hi[255] : (int)h_lo[255];
+	// With two passes the high-byte bucket 255 holds only misses as long as nmat < 0xFF00.
+	int nres = n - misses;
+	*out_results = nres;
+	if (nres > 0) {
+		hipLaunchKernelGGL(k_emit_records, dim3(nblocks(nres, BLOCK)), dim3(BLOCK), 0, st, sv, d_org, d_dir, d_hits, perm,
+		                   nres, d_records);
+		RT_HIP_CHECK(hipGetLastError());
+	}
+	// Cumulative end offsets for the materials that have hits (std::map holds only those).
+	std::vector<rt_result_offset> off;
+	if (!two_pass) {
+		int run = 0;
+		for (int m = 0; m < 255 && m < nmat; ++m)
+			if (h_lo[m]) { run += (int)h_lo[m]; rt_result_offset o; o.material = (uint32_t)m; o.end = run; off.push_back(o); }
+	} else {
+		// counts per full key need the sorted keys; recompute from the permutation on the host side
+		// would cost a download -- instead count materials with a tiny second histogram on device:
+		// (rare path: >= 255 materials) download the per-ray material ids.
+		std::vector<Hit> hh((size_t)n);
+		RT_HIP_CHECK(hipMemcpy(hh.data(), d_hits, (size_t)n * sizeof(Hit), hipMemcpyDeviceToHost));
+		std::vector<TriPos> tp((size_t)ctx->num_tris);
+		RT_HIP_CHECK(hipMemcpy(tp.data(), ctx->d_tri_pos.p, tp.size() * sizeof(TriPos), hipMemcpyDeviceToHost));
+		std::vector<int> cnt((size_t)nmat, 0);
+		for (int i = 0; i < n; ++i)
+			if (hh[i].prim != RT_MISS) {
+				int m;
+				memcpy(&m, &tp[hh[i].prim].p0.w, 4);
+				if (m >= 0 && m < nmat) ++cnt[m];
+			}
+		int run = 0;
+		for (int m = 0; m < nmat; ++m)
+			if (cnt[m]) { run += cnt[m]; rt_result_offset o; o.material = (uint32_t)m; o.end = run; off.push_back(o); }
+	}
+	*out_groups = (int)off.size();
+	if (!off.empty() && d_offsets)
+		RT_HIP_CHECK(hipMemcpyAsync(d_offsets, off.data(), off.size() * sizeof(rt_result_offset), hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	return RT_HIP_OK;
+}
+
+int rt_gbuffer_select(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n, int interlace,
+                      int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* out_count)
+{
+	*out_count = 0;
+	if (n <= 0) return RT_HIP_OK;
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_keys.reserve((size_t)n * 4));
+	RT_CHECK(ctx->d_rank.reserve((size_t)n * 4));
+	RT_CHECK(ctx->d_counts.reserve(2 * 256 * 4));
+	uint32_t* digit = ctx->d_keys.as<uint32_t>();
+	uint32_t* dest = ctx->d_rank.as<uint32_t>();
+	uint32_t* totals = ctx->d_counts.as<uint32_t>();
+	const int g = nblocks(n, BLOCK);
+	hipLaunchKernelGGL(k_select_digit, dim3(g), dim3(BLOCK), 0, st, d_nrm_rgba, n, interlace, phase, digit);
+	RT_CHECK(rt_multisplit256(ctx, digit, n, dest, totals));
+	hipLaunchKernelGGL(k_select_scatter, dim3(g), dim3(BLOCK), 0, st, d_nrm_rgba, d_pos_rgb, digit, dest, n, d_pos_out,
+	                   d_nrm_out, d_index_out);
+	RT_HIP_CHECK(hipGetLastError());
+	uint32_t cnt = 0;
+	RT_HIP_CHECK(hipMemcpyAsync(&cnt, totals, 4, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	*out_count = (int)cnt;
+	return RT_HIP_OK;
+}
+
+int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb)
+{
+	SceneView sv = rt_scene_view(ctx);
+	float tanfov = tanf(fov);  // Camera::setFOV (data/camera.cpp:41-44)
+	size_t lds = sv.use_bvh ? (size_t)sv.stack_depth * TRACE_BLOCK * sizeof(int) : 0;
+	hipLaunchKernelGGL(k_primary_gbuffer, dim3(nblocks((int64_t)w * h, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, ctx->stream,
+	                   sv, tanfov, w, h, d_nrm_rgba, d_pos_rgb);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+// Resolve the hits of a ray queue into HitInfo (triangles via the trace kernels, spheres inline).
+static int trace_queue(rt_hip_ctx* ctx, const SceneView& sv, const float* q_org, const float* q_dir, int nq,
+                       HitInfo* d_hi)
+{
+	if (nq <= 0) return RT_HIP_OK;
+	if (sv.num_spheres > 0 && sv.num_tris == 0) {
+		hipLaunchKernelGGL(k_queue_sphere_hits, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, q_dir, nq, d_hi);
+		RT_HIP_CHECK(hipGetLastError());
+		ctx->stats.rays_closest += nq;
+		return RT_HIP_OK;
+	}
+	RT_CHECK(ctx->d_hits.reserve((size_t)nq * sizeof(Hit)));
+	RT_CHECK(rt_launch_closest(ctx, q_org, q_dir, nq, ctx->d_hits.as<Hit>()));
+	hipLaunchKernelGGL(k_resolve, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, ctx->d_hits.as<Hit>(), nq, d_hi);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
+                    int rank, int nranks, uint8_t* d_rgba)
+{
+	hipStream_t st = ctx->stream;
+	SceneView sv = rt_scene_view(ctx);
+	const int bounces = ctx->cfg.bounces;
+	const int npix = w * h;
+	ctx->last_frame_rays = 0;
+	if (npix <= 0 || bounces <= 0) return RT_HIP_OK;
+	if (bounces > 8) { rt_set_error("bounces > 8 not supported"); return RT_HIP_ERR_LIMIT; }
+	if (sv.num_lights > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
+	const bool spheres = sv.num_spheres > 0 && sv.num_tris == 0;
+
+	// level arrays: level L can hold at most 2^L * npix nodes, but only what was spawned is used;
+	// capacity is grown on demand after each level's count is known.
+	std::vector<int> count(bounces + 1, 0);
+	std::vector<size_t> geo_off(bounces + 1, 0);
+	count[0] = npix;
+	size_t total_nodes = 0;
+	// reserve level 0 now, deeper levels as they appear (one DevBuf, offsets in nodes)
+	auto ensure_nodes = [&](size_t nodes) -> int {
+		RT_CHECK(ctx->d_nodes_a.reserve(nodes * sizeof(NodeGeo)));
+		RT_CHECK(ctx->d_nodes_b.reserve(nodes * sizeof(NodeShade)));
+		RT_CHECK(ctx->d_gate.reserve(nodes * sizeof(int)));
+		return RT_HIP_OK;
+	};
+	// worst case for the next level is 2 children per node; reserve level 0 + level 1 bound up front
+	RT_CHECK(ensure_nodes((size_t)npix * (bounces > 1 ? 3 : 1)));
+	RT_CHECK(ctx->d_qcount.reserve(64));
+	int* qcount = ctx->d_qcount.as<int>();  // [0] ray queue count, [1] child count
+	RT_CHECK(ctx->d_occ.reserve((size_t)npix * 4 * 2));
+
+	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(npix, BLOCK)), dim3(BLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, tile, rank,
+	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>());
+	RT_HIP_CHECK(hipGetLastError());
+
+	int64_t rays = 0;
+	int levels = 0;
+	for (int L = 0; L < bounces; ++L) {
+		const int n = count[L];
+		if (n == 0) break;
+		levels = L + 1;
+		total_nodes = geo_off[L] + (size_t)n;
+		const bool recurse = (L + 1 < bounces);
+		// (re)fetch base pointers: reserve() may have moved the buffers
+		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + geo_off[L];
+		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + geo_off[L];
+		int* gate = ctx->d_gate.as<int>() + geo_off[L];
+
+		const float* photon_rgb = nullptr;
+		unsigned int* occl = nullptr;
+		if (ctx->cfg.use_photon_map) {
+			RT_CHECK(ctx->d_org.reserve((size_t)n * 12));
+			RT_CHECK(ctx->d_dir.reserve((size_t)n * 12));
+			RT_CHECK(ctx->d_accum.reserve((size_t)n * 12));
+			hipLaunchKernelGGL(k_node_points, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, geo, n, ctx->d_org.as<float>(),
+			                   ctx->d_dir.as<float>());
+			RT_CHECK(rt_photon_gather(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), n, ctx->cfg.photon_estimate,
+			                          ctx->cfg.photon_radius, ctx->d_accum.as<float>()));
+			photon_rgb = ctx->d_accum.as<float>();
+		} else if (ctx->cfg.do_shadows && sv.num_lights > 0) {
+			RT_CHECK(ctx->d_occ.reserve((size_t)n * 4));
+			occl = ctx->d_occ.as<unsigned int>();
+			RT_HIP_CHECK(hipMemsetAsync(occl, 0, (size_t)n * 4, st));
+			int64_t total = (int64_t)n * sv.num_lights;
+			size_t lds = sv.use_bvh ? (size_t)sv.stack_depth * TRACE_BLOCK * sizeof(int) : 0;
+			RT_CHECK(rt_begin_trace_timing(ctx));
+			hipLaunchKernelGGL(k_shadow, dim3(nblocks(total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n, occl);
+			RT_HIP_CHECK(hipGetLastError());
+			RT_CHECK(rt_end_trace_timing(ctx));
+			// rays are only issued for active nodes; counted exactly below from the node census
+		}
+
+		// queue buffers sized for one ray per node
+		RT_CHECK(ctx->d_rays_q.reserve((size_t)n * 24));
+		RT_CHECK(ctx->d_ray_parent.reserve((size_t)n * 4));
+		RT_CHECK(ctx->d_records.reserve((size_t)n * sizeof(HitInfo)));
+		float* q_org = ctx->d_rays_q.as<float>();
+		float* q_dir = q_org + (size_t)n * 3;
+		int* q_parent = ctx->d_ray_parent.as<int>();
+		HitInfo* d_hi = ctx->d_records.as<HitInfo>();
+
+		RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 16, st));
+		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, occl,
+		                   photon_rgb, ctx->cfg.do_shadows, recurse ? 1 : 0, gate, q_org, q_dir, q_parent, qcount);
+		RT_HIP_CHECK(hipGetLastError());
+		if (!recurse) break;
+
+		// children of this level are appended after it
+		geo_off[L + 1] = geo_off[L] + (size_t)n;
+		int h_counts[4] = {0, 0, 0, 0};
+		RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
+		RT_HIP_CHECK(hipStreamSynchronize(st));
+		int nq = h_counts[0];
+		RT_CHECK(ensure_nodes(geo_off[L + 1] + (size_t)2 * n));  // both branches can at most add n each
+		geo = ctx->d_nodes_a.as<NodeGeo>() + geo_off[L];
+		gate = ctx->d_gate.as<int>() + geo_off[L];
+		NodeGeo* child_geo = ctx->d_nodes_a.as<NodeGeo>() + geo_off[L + 1];
+		if (nq > 0) {
+			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
+			rays += nq;
+			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, st, d_hi, q_dir, q_parent, nq, 0,
+			                   gate, child_geo, qcount + 1);
+			RT_HIP_CHECK(hipGetLastError());
+		}
+		// refraction, gated after the reflection hits are known (Q9)
+		RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 4, st));
+		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, n, gate, q_org, q_dir,
+		                   q_parent, qcount);
+		RT_HIP_CHECK(hipGetLastError());
+		RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
+		RT_HIP_CHECK(hipStreamSynchronize(st));
+		nq = h_counts[0];
+		if (nq > 0) {
+			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
+			rays += nq;
+			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, st, d_hi, q_dir, q_parent, nq, 1,
+			                   gate, child_geo, qcount + 1);
+			RT_HIP_CHECK(hipGetLastError());
+			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
+			RT_HIP_CHECK(hipStreamSynchronize(st));
+		}
+		count[L + 1] = h_counts[1];
+	}
+	(void)total_nodes;
+	(void)spheres;
+
+	// shadow-ray count: every active node of every shaded level issues num_lights rays
+	// bottom-up combine
+	for (int L = levels - 1; L >= 0; --L) {
+		const int n = count[L];
+		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + geo_off[L];
+		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + geo_off[L];
+		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + geo_off[L - 1] : nullptr;
+		hipLaunchKernelGGL(k_combine, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, L, pshade, d_rgba,
+		                   (float*)nullptr);
+		RT_HIP_CHECK(hipGetLastError());
+	}
+	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+	RT_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+	float ms = 0;
+	RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+	ctx->stats.frame_ms += ms;
+	ctx->stats.frames += 1;
+	ctx->last_frame_rays = rays;  // shadow rays are added by the caller-visible census in rt_api.hip
+	// stash per-level counts for the census
+	ctx->last_count = levels;
+	RT_CHECK(rt_collect_timing(ctx));
+	return RT_HIP_OK;
+}

@@ -1,0 +1,199 @@
+// raytracer_amd/csrc/k_trace.hip -- intersection kernels: brute force (geometry through the
+// scalar/LDS path), LBVH traversal with a per-lane LDS stack, spheres.  FP32 VALU only; MFMA is
+// not used because nothing here is a dense contraction.
+//
+// Results restate, bit for bit, the reference's closest-hit / any-hit arithmetic:
+//   closest  rt_raytracer.cpp:315-370 (naiveTrace) / rt_accel_array.cpp:75-137
+//   occlude  rt_accel_array.cpp:45-73
+//   spheres  rt_accel_spheres.cpp:38-104
+#include "rt_ctx.h"
+#include "rt_trace_dev.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int BVH_BLOCK = 128;
+
+// ---- brute force ------------------------------------------------------------------------------
+// One ray per lane; the triangle index is wave-uniform, so the 48-byte records come in through
+// scalar loads (constant across the wave) and feed the VALU as SGPR operands.
+template <int MODE>  // 0 closest, 1 any (intersect tests), 2 AccelArray::occlude
+__global__ __launch_bounds__(BLOCK) void k_brute(const TriIsect* __restrict__ tris, int num_tris,
+                                                 const float* __restrict__ org, const float* __restrict__ dir,
+                                                 int n, TraceParams tp, Hit* __restrict__ hits,
+                                                 uint8_t* __restrict__ occ)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
+	Hit best;
+	best.prim = RT_MISS; best.t = tp.t_max; best.u = 0; best.v = 0;
+	bool any = false;
+	for (int k = 0; k < num_tris; ++k) {
+		float4 a = tris[k].a, b = tris[k].b, c = tris[k].c;
+		f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+		if (MODE == 0) {
+			mt_closest(O, D, v0, e1, e2, __float_as_uint(a.w), tp, best);
+		} else if (MODE == 1) {
+			if (mt_any(O, D, v0, e1, e2, tp)) { any = true; break; }
+		} else {
+			if (mt_occlude_ref(O, D, v0, e1, e2, tp.eps_det)) { any = true; break; }
+		}
+	}
+	if (MODE == 0) {
+		if (best.prim == RT_MISS) best.t = __builtin_inff();
+		hits[i] = best;
+	} else {
+		occ[i] = any ? 1 : 0;
+	}
+}
+
+// ---- LBVH traversal ---------------------------------------------------------------------------
+template <bool ANY, bool CENSUS>
+__global__ __launch_bounds__(BVH_BLOCK) void k_bvh(SceneView sv, const float* __restrict__ org,
+                                                   const float* __restrict__ dir, int n, Hit* __restrict__ hits,
+                                                   uint8_t* __restrict__ occ, uint32_t* __restrict__ nv,
+                                                   uint32_t* __restrict__ nt)
+{
+	extern __shared__ __attribute__((aligned(16))) int smem[];
+	int i = blockIdx.x * BVH_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
+	Hit best;
+	uint32_t cn = 0, ct = 0;
+	bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, smem + threadIdx.x, BVH_BLOCK, cn, ct);
+	if (CENSUS) { nv[i] = cn; nt[i] = ct; }
+	if (ANY) { if (occ) occ[i] = any ? 1 : 0; }
+	else if (hits) hits[i] = best;
+}
+
+// ---- spheres ----------------------------------------------------------------------------------
+// AccelSpheres::intersect (rt_accel_spheres.cpp:58-104): Ro = direction (reference quirk Q5), the
+// FIRST sphere in list order that passes wins (Q6).
+__global__ __launch_bounds__(BLOCK) void k_sphere_intersect(const SphereRec* __restrict__ sph, int ns,
+                                                            const float* __restrict__ dir, int n,
+                                                            int* __restrict__ index, float* __restrict__ pos,
+                                                            float* __restrict__ nrm)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	f3 Rd = ld3(dir + 3 * (size_t)i);
+	int found = -1;
+	f3 X = mk3(0, 0, 0), N = mk3(0, 0, 0);
+	for (int k = 0; k < ns; ++k) {
+		if (sphere_test_ref(sph[k], Rd, Rd, X, N)) { found = k; break; }
+	}
+	index[i] = found;
+	if (found >= 0) { st3(pos + 3 * (size_t)i, X); st3(nrm + 3 * (size_t)i, N); }
+}
+
+// AccelSpheres::occlude (rt_accel_spheres.cpp:38-56): discriminant of the infinite line.
+__global__ __launch_bounds__(BLOCK) void k_sphere_occlude(const SphereRec* __restrict__ sph, int ns,
+                                                          const float* __restrict__ org,
+                                                          const float* __restrict__ dir, int n,
+                                                          uint8_t* __restrict__ occ)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	f3 Ro = ld3(org + 3 * (size_t)i), Rd = ld3(dir + 3 * (size_t)i);
+	bool any = false;
+	for (int k = 0; k < ns; ++k) {
+		if (sphere_occlude_ref(sph[k], Ro, Rd)) { any = true; break; }
+	}
+	occ[i] = any ? 1 : 0;
+}
+
+inline int nblocks(int n, int b) { return (n + b - 1) / b; }
+
+}  // namespace
+
+int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, Hit* d_hits)
+{
+	if (n <= 0) return RT_HIP_OK;
+	SceneView sv = rt_scene_view(ctx);
+	RT_CHECK(rt_begin_trace_timing(ctx));
+	if (sv.use_bvh) {
+		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
+		hipLaunchKernelGGL((k_bvh<false, false>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		                   d_org, d_dir, n, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+	} else {
+		hipLaunchKernelGGL((k_brute<0>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv.tris, sv.num_tris,
+		                   d_org, d_dir, n, sv.tp, d_hits, (uint8_t*)nullptr);
+	}
+	RT_HIP_CHECK(hipGetLastError());
+	RT_CHECK(rt_end_trace_timing(ctx));
+	ctx->stats.rays_closest += n;
+	return RT_HIP_OK;
+}
+
+int rt_launch_any(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ)
+{
+	if (n <= 0) return RT_HIP_OK;
+	SceneView sv = rt_scene_view(ctx);
+	RT_CHECK(rt_begin_trace_timing(ctx));
+	if (sv.use_bvh) {
+		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
+		hipLaunchKernelGGL((k_bvh<true, false>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		                   d_org, d_dir, n, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr);
+	} else {
+		hipLaunchKernelGGL((k_brute<1>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv.tris, sv.num_tris,
+		                   d_org, d_dir, n, sv.tp, (Hit*)nullptr, d_occ);
+	}
+	RT_HIP_CHECK(hipGetLastError());
+	RT_CHECK(rt_end_trace_timing(ctx));
+	ctx->stats.rays_any += n;
+	return RT_HIP_OK;
+}
+
+// AccelArray::occlude has no t test, so no BVH pruning applies: every triangle whose plane the
+// LINE crosses inside the triangle occludes.  It is evaluated exhaustively (API-parity path, not
+// a hot one: the shading loop uses rt_launch_any).
+int rt_launch_occlude_ref(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ)
+{
+	if (n <= 0) return RT_HIP_OK;
+	SceneView sv = rt_scene_view(ctx);
+	hipLaunchKernelGGL((k_brute<2>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv.tris, sv.num_tris,
+	                   d_org, d_dir, n, sv.tp, (Hit*)nullptr, d_occ);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+int rt_launch_census(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, int any_hit, uint32_t* d_nv,
+                     uint32_t* d_nt)
+{
+	if (n <= 0) return RT_HIP_OK;
+	SceneView sv = rt_scene_view(ctx);
+	if (!sv.use_bvh) {
+		rt_set_error("census needs the LBVH (accel = brute force)");
+		return RT_HIP_ERR_STATE;
+	}
+	size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
+	if (any_hit)
+		hipLaunchKernelGGL((k_bvh<true, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt);
+	else
+		hipLaunchKernelGGL((k_bvh<false, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+int rt_launch_sphere_intersect(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, int* d_index,
+                               float* d_pos, float* d_nrm)
+{
+	(void)d_org;  // the reference replaces the origin by the direction (rt_accel_spheres.cpp:68)
+	if (n <= 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_sphere_intersect, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+	                   ctx->d_spheres.as<SphereRec>(), (int)ctx->spheres.size(), d_dir, n, d_index, d_pos, d_nrm);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+int rt_launch_sphere_occlude(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ)
+{
+	if (n <= 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_sphere_occlude, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+	                   ctx->d_spheres.as<SphereRec>(), (int)ctx->spheres.size(), d_org, d_dir, n, d_occ);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}

@@ -1,0 +1,703 @@
+// raytracer_amd/csrc/rt_api.hip -- the C ABI declared in include/rt_hip.h: context life cycle,
+// scene ingestion, and the host orchestration of the kernels in k_*.hip.  No CPU fallback lives
+// here: every entry point either runs HIP kernels or fails with an error code.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <cmath>
+#include <limits>
+
+#include "rt_ctx.h"
+
+int rt_fill_sphere_records(rt_hip_ctx* ctx, const int* d_index, const float* d_pos, const float* d_nrm, int n,
+                           rt_ray* d_rays, uint8_t* d_flag, uint32_t* d_material);
+
+static thread_local char g_err[512] = "";
+
+void rt_set_error(const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+int DevBuf::reserve(size_t bytes)
+{
+	if (bytes <= cap && p) return RT_HIP_OK;
+	size_t want = bytes < 256 ? 256 : bytes;
+	if (p) want = std::max(want, cap + cap / 2);  // geometric growth
+	void* np = nullptr;
+	hipError_t e = hipMalloc(&np, want);
+	if (e != hipSuccess) {
+		rt_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+		return RT_HIP_ERR_HIP;
+	}
+	if (p) {
+		// contents are preserved (level arrays of a frame grow while earlier levels are live)
+		e = hipDeviceSynchronize();
+		if (e == hipSuccess) e = hipMemcpy(np, p, cap, hipMemcpyDeviceToDevice);
+		if (e != hipSuccess) {
+			rt_set_error("DevBuf grow copy failed: %s", hipGetErrorString(e));
+			(void)hipFree(np);
+			return RT_HIP_ERR_HIP;
+		}
+		(void)hipFree(p);
+	}
+	p = np;
+	cap = want;
+	return RT_HIP_OK;
+}
+
+void DevBuf::release()
+{
+	if (p) (void)hipFree(p);
+	p = nullptr;
+	cap = 0;
+}
+
+int rt_ensure_pinned(void** p, size_t* cap, size_t bytes)
+{
+	if (*p && *cap >= bytes) return RT_HIP_OK;
+	if (*p) (void)hipHostFree(*p);
+	*p = nullptr;
+	*cap = 0;
+	size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+	RT_HIP_CHECK(hipHostMalloc(p, want, hipHostMallocDefault));
+	*cap = want;
+	return RT_HIP_OK;
+}
+
+SceneView rt_scene_view(const rt_hip_ctx* ctx)
+{
+	SceneView sv;
+	sv.nodes = ctx->d_nodes.as<BvhNode>();
+	sv.tris = ctx->d_tri_isect.as<TriIsect>();
+	sv.tri_pos = ctx->d_tri_pos.as<TriPos>();
+	sv.tri_attr = ctx->d_tri_attr.as<TriAttr>();
+	sv.spheres = ctx->d_spheres.as<SphereRec>();
+	sv.materials = ctx->d_materials.as<MaterialRec>();
+	sv.lights = ctx->d_lights.as<LightRec>();
+	sv.num_tris = ctx->cfg.geometry == RT_HIP_SPHERES ? 0 : ctx->num_tris;
+	sv.num_spheres = ctx->cfg.geometry == RT_HIP_SPHERES ? (int)ctx->spheres.size() : 0;
+	sv.num_materials = (int)ctx->materials.size() + sv.num_spheres;
+	sv.num_lights = (int)ctx->lights.size();
+	sv.use_bvh = ctx->use_bvh;
+	sv.stack_depth = ctx->bvh_depth + 1;
+	sv.tp.eps_det = ctx->cfg.eps_det;
+	sv.tp.eps_t = ctx->cfg.eps_t;
+	sv.tp.t_max = ctx->cfg.t_max;
+	return sv;
+}
+
+// ---- kernel timing (profile mode) -------------------------------------------------------------
+int rt_begin_trace_timing(rt_hip_ctx* ctx)
+{
+	if (!ctx->cfg.profile) return RT_HIP_OK;
+	if (ctx->trace_events_used == ctx->trace_events.size()) {
+		hipEvent_t a, b;
+		RT_HIP_CHECK(hipEventCreate(&a));
+		RT_HIP_CHECK(hipEventCreate(&b));
+		ctx->trace_events.push_back(std::make_pair(a, b));
+	}
+	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].first, ctx->stream));
+	return RT_HIP_OK;
+}
+
+int rt_end_trace_timing(rt_hip_ctx* ctx)
+{
+	if (!ctx->cfg.profile) return RT_HIP_OK;
+	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].second, ctx->stream));
+	++ctx->trace_events_used;
+	ctx->stats.trace_launches += 1;
+	return RT_HIP_OK;
+}
+
+// Fold the pending event pairs into stats (requires the stream to be idle or syncs on the events).
+int rt_collect_timing(rt_hip_ctx* ctx)
+{
+	if (!ctx->cfg.profile) return RT_HIP_OK;
+	for (size_t i = 0; i < ctx->trace_events_used; ++i) {
+		RT_HIP_CHECK(hipEventSynchronize(ctx->trace_events[i].second));
+		float ms = 0;
+		RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->trace_events[i].first, ctx->trace_events[i].second));
+		ctx->stats.trace_ms += ms;
+	}
+	ctx->trace_events_used = 0;
+	return RT_HIP_OK;
+}
+
+// The float threshold F such that (x < F) == ((double)x < d) for every float x.
+static float float_threshold_of_double(double d)
+{
+	float f = (float)d;
+	if ((double)f < d) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+	return f;
+}
+
+static int check_ctx(rt_hip_ctx* ctx)
+{
+	if (!ctx) { rt_set_error("null context"); return RT_HIP_ERR_ARG; }
+	RT_HIP_CHECK(hipSetDevice(ctx->cfg.device));
+	return RT_HIP_OK;
+}
+
+static int check_ready(rt_hip_ctx* ctx)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (ctx->scene_dirty) { rt_set_error("scene changed: call rt_hip_update() before tracing"); return RT_HIP_ERR_STATE; }
+	return RT_HIP_OK;
+}
+
+extern "C" {
+
+const char* rt_hip_last_error(void) { return g_err; }
+
+int rt_hip_default_config(rt_hip_config* cfg)
+{
+	if (!cfg) { rt_set_error("null config"); return RT_HIP_ERR_ARG; }
+	memset(cfg, 0, sizeof(*cfg));
+	cfg->device = 0;
+	cfg->geometry = RT_HIP_TRIANGLES;
+	cfg->accel = RT_HIP_ACCEL_AUTO;
+	cfg->use_model_mat = 1;
+	cfg->eps_det = std::numeric_limits<float>::epsilon();
+	cfg->eps_t = std::numeric_limits<float>::epsilon();
+	cfg->t_max = std::numeric_limits<float>::infinity();
+	cfg->bounces = 2;
+	cfg->do_shadows = 0;
+	cfg->use_photon_map = 0;
+	cfg->photon_count = 10000;
+	cfg->photon_estimate = 100;
+	cfg->photon_radius = 1.0f;
+	cfg->photon_max_dist = 12.0f;
+	cfg->photon_absorb = 0.6f;
+	cfg->seed = 42;
+	cfg->profile = 0;
+	return RT_HIP_OK;
+}
+
+int rt_hip_array_config(rt_hip_config* cfg)
+{
+	RT_CHECK(rt_hip_default_config(cfg));
+	cfg->use_model_mat = 0;
+	cfg->eps_det = float_threshold_of_double(0.00001);
+	cfg->eps_t = float_threshold_of_double(0.00001);
+	cfg->t_max = 1000000.0f;
+	return RT_HIP_OK;
+}
+
+int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out)
+{
+	if (!cfg || !out) { rt_set_error("null argument"); return RT_HIP_ERR_ARG; }
+	*out = nullptr;
+	int ndev = 0;
+	RT_HIP_CHECK(hipGetDeviceCount(&ndev));
+	if (ndev <= 0) { rt_set_error("no HIP device visible: librt_hip has no CPU fallback"); return RT_HIP_ERR_HIP; }
+	if (cfg->device < 0 || cfg->device >= ndev) { rt_set_error("device %d out of range (%d devices)", cfg->device, ndev); return RT_HIP_ERR_ARG; }
+	RT_HIP_CHECK(hipSetDevice(cfg->device));
+	rt_hip_ctx* ctx = new rt_hip_ctx();
+	ctx->cfg = *cfg;
+	memset(&ctx->stats, 0, sizeof(ctx->stats));
+	hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+	if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+	if (e == hipSuccess) e = hipHostMalloc(&ctx->h_small, 4096, hipHostMallocDefault);
+	if (e != hipSuccess) {
+		rt_set_error("context creation failed: %s", hipGetErrorString(e));
+		delete ctx;
+		return RT_HIP_ERR_HIP;
+	}
+	*out = ctx;
+	return RT_HIP_OK;
+}
+
+int rt_hip_destroy(rt_hip_ctx* ctx)
+{
+	if (!ctx) return RT_HIP_OK;
+	(void)hipSetDevice(ctx->cfg.device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	DevBuf* bufs[] = {&ctx->d_verts, &ctx->d_normals, &ctx->d_texcoords, &ctx->d_faces, &ctx->d_mesh_of_tri, &ctx->d_mesh_xf,
+	                  &ctx->d_tri_pos, &ctx->d_tri_attr, &ctx->d_tri_isect, &ctx->d_tri_box, &ctx->d_nodes, &ctx->d_spheres,
+	                  &ctx->d_materials, &ctx->d_lights, &ctx->d_morton, &ctx->d_morton_tmp, &ctx->d_order, &ctx->d_order_tmp,
+	                  &ctx->d_hist, &ctx->d_flags, &ctx->d_parent_leaf, &ctx->d_bounds, &ctx->d_misc, &ctx->d_org, &ctx->d_dir,
+	                  &ctx->d_hits, &ctx->d_occ, &ctx->d_in_a, &ctx->d_in_b, &ctx->d_records, &ctx->d_offsets, &ctx->d_keys,
+	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
+	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
+	                  &ctx->d_cell_start, &ctx->d_photon_tmp};
+	for (DevBuf* b : bufs) b->release();
+	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+	if (ctx->h_records) (void)hipHostFree(ctx->h_records);
+	if (ctx->h_offsets) (void)hipHostFree(ctx->h_offsets);
+	if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return RT_HIP_OK;
+}
+
+int rt_hip_set_config(rt_hip_ctx* ctx, const rt_hip_config* cfg)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (!cfg) { rt_set_error("null config"); return RT_HIP_ERR_ARG; }
+	ctx->cfg.bounces = cfg->bounces;
+	ctx->cfg.do_shadows = cfg->do_shadows;
+	ctx->cfg.use_photon_map = cfg->use_photon_map;
+	ctx->cfg.photon_count = cfg->photon_count;
+	ctx->cfg.photon_estimate = cfg->photon_estimate;
+	ctx->cfg.photon_radius = cfg->photon_radius;
+	ctx->cfg.photon_max_dist = cfg->photon_max_dist;
+	ctx->cfg.photon_absorb = cfg->photon_absorb;
+	ctx->cfg.seed = cfg->seed;
+	ctx->cfg.profile = cfg->profile;
+	ctx->cfg.eps_det = cfg->eps_det;
+	ctx->cfg.eps_t = cfg->eps_t;
+	ctx->cfg.t_max = cfg->t_max;
+	return RT_HIP_OK;
+}
+
+// ---- scene ---------------------------------------------------------------------------------
+int rt_hip_set_materials(rt_hip_ctx* ctx, const rt_material* materials, int n)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (n < 0 || (n > 0 && !materials)) { rt_set_error("bad material table"); return RT_HIP_ERR_ARG; }
+	ctx->materials.assign(materials, materials + n);
+	ctx->scene_dirty = true;
+	return RT_HIP_OK;
+}
+
+int rt_hip_set_lights(rt_hip_ctx* ctx, const rt_light* lights, int n)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (n < 0 || (n > 0 && !lights)) { rt_set_error("bad light table"); return RT_HIP_ERR_ARG; }
+	ctx->lights.assign(lights, lights + n);
+	ctx->scene_dirty = true;
+	return RT_HIP_OK;
+}
+
+int rt_hip_add_sphere(rt_hip_ctx* ctx, float x, float y, float z, float radius)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (!ctx->sphere_rng_seeded) {
+		srand(420);  // AccelSpheres::AccelSpheres (rt_accel_spheres.cpp:11)
+		ctx->sphere_rng_seeded = true;
+	}
+	HostSphere s;
+	s.c[0] = x; s.c[1] = y; s.c[2] = z; s.r = radius;
+	// Vector3f(rand()%256, rand()%256, rand()%256): g++ evaluates the arguments right to left,
+	// so the first draw is the blue channel (pinned against the compiled reference).
+	s.diffuse[2] = (float)(rand() % 256);
+	s.diffuse[1] = (float)(rand() % 256);
+	s.diffuse[0] = (float)(rand() % 256);
+	ctx->spheres.push_back(s);
+	ctx->scene_dirty = true;
+	return (int)ctx->spheres.size() - 1;
+}
+
+int rt_hip_add_mesh(rt_hip_ctx* ctx, const float* verts, const float* normals, const float* texcoords, int nverts,
+                    const uint32_t* faces, int nfaces, const float* model_mat16, int material_id,
+                    const float* position3)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (nverts < 0 || nfaces < 0 || (nverts > 0 && (!verts || !normals || !texcoords)) || (nfaces > 0 && !faces)) {
+		rt_set_error("bad mesh arrays");
+		return RT_HIP_ERR_ARG;
+	}
+	for (int i = 0; i < nfaces * 3; ++i)
+		if (faces[i] >= (uint32_t)nverts) { rt_set_error("face index %u out of range (%d verts)", faces[i], nverts); return RT_HIP_ERR_ARG; }
+	HostMesh m;
+	m.verts.assign(verts, verts + (size_t)nverts * 3);
+	m.normals.assign(normals, normals + (size_t)nverts * 3);
+	m.texcoords.assign(texcoords, texcoords + (size_t)nverts * 2);
+	m.faces.assign(faces, faces + (size_t)nfaces * 3);
+	if (model_mat16) memcpy(m.model, model_mat16, sizeof(m.model));
+	else { memset(m.model, 0, sizeof(m.model)); m.model[0] = m.model[5] = m.model[10] = m.model[15] = 1.0f; }
+	m.material = material_id;
+	for (int k = 0; k < 3; ++k) m.position[k] = position3 ? position3[k] : 0.0f;
+	m.first_tri = 0;
+	m.vert_offset = 0;
+	ctx->meshes.push_back(m);
+	if (ctx->cfg.geometry == RT_HIP_SPHERES) {
+		// AccelSpheres::addMesh: a unit sphere at Mesh::position (rt_accel_spheres.cpp:27-31)
+		int s = rt_hip_add_sphere(ctx, m.position[0], m.position[1], m.position[2], 1.0f);
+		if (s < 0) return s;
+	}
+	ctx->scene_dirty = true;
+	return (int)ctx->meshes.size() - 1;
+}
+
+int rt_hip_set_model_mat(rt_hip_ctx* ctx, int mesh_id, const float* model_mat16)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (mesh_id < 0 || mesh_id >= (int)ctx->meshes.size() || !model_mat16) { rt_set_error("bad mesh id"); return RT_HIP_ERR_ARG; }
+	memcpy(ctx->meshes[mesh_id].model, model_mat16, sizeof(float) * 16);
+	ctx->scene_dirty = true;
+	return RT_HIP_OK;
+}
+
+int rt_hip_update(rt_hip_ctx* ctx)
+{
+	RT_CHECK(check_ctx(ctx));
+	for (const HostMesh& m : ctx->meshes)
+		if (ctx->cfg.geometry == RT_HIP_TRIANGLES && !m.faces.empty() &&
+		    (m.material < 0 || m.material >= (int)ctx->materials.size())) {
+			rt_set_error("mesh material id %d outside the material table (%zu)", m.material, ctx->materials.size());
+			return RT_HIP_ERR_ARG;
+		}
+	RT_CHECK(rt_build_geometry(ctx));
+	ctx->scene_dirty = false;
+	return RT_HIP_OK;
+}
+
+// ---- IAccel batch entries ---------------------------------------------------------------------
+int rt_hip_intersect(rt_hip_ctx* ctx, rt_ray* rays, int n, uint8_t* hit_out, uint32_t* material_out, rt_hit* hits_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (n < 0 || (n > 0 && !rays)) { rt_set_error("bad ray array"); return RT_HIP_ERR_ARG; }
+	if (n == 0) return RT_HIP_OK;
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_records.reserve((size_t)n * sizeof(rt_ray)));
+	RT_CHECK(ctx->d_org.reserve((size_t)n * 12));
+	RT_CHECK(ctx->d_dir.reserve((size_t)n * 12));
+	RT_CHECK(ctx->d_hits.reserve((size_t)n * sizeof(Hit)));
+	RT_CHECK(ctx->d_occ.reserve((size_t)n));
+	RT_CHECK(ctx->d_keys.reserve((size_t)n * 4));
+	rt_ray* d_rays = ctx->d_records.as<rt_ray>();
+	RT_HIP_CHECK(hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(rt_ray), hipMemcpyHostToDevice, st));
+	RT_CHECK(rt_launch_split_rays(ctx, d_rays, n, ctx->d_org.as<float>(), ctx->d_dir.as<float>()));
+	if (ctx->cfg.geometry == RT_HIP_SPHERES) {
+		RT_CHECK(ctx->d_in_a.reserve((size_t)n * 4));
+		RT_CHECK(ctx->d_in_b.reserve((size_t)n * 24));
+		int* d_index = ctx->d_in_a.as<int>();
+		float* d_pos = ctx->d_in_b.as<float>();
+		float* d_nrm = d_pos + (size_t)n * 3;
+		RT_CHECK(rt_launch_sphere_intersect(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), n, d_index, d_pos, d_nrm));
+		RT_CHECK(rt_fill_sphere_records(ctx, d_index, d_pos, d_nrm, n, d_rays, ctx->d_occ.as<uint8_t>(), ctx->d_keys.as<uint32_t>()));
+		if (hits_out) memset(hits_out, 0xFF, (size_t)n * sizeof(rt_hit));
+	} else {
+		RT_CHECK(rt_launch_closest(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), n, ctx->d_hits.as<Hit>()));
+		RT_CHECK(rt_launch_fill_records(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), ctx->d_hits.as<Hit>(), n, d_rays,
+		                                ctx->d_occ.as<uint8_t>(), ctx->d_keys.as<uint32_t>()));
+		if (hits_out) RT_HIP_CHECK(hipMemcpyAsync(hits_out, ctx->d_hits.p, (size_t)n * sizeof(rt_hit), hipMemcpyDeviceToHost, st));
+	}
+	RT_HIP_CHECK(hipMemcpyAsync(rays, d_rays, (size_t)n * sizeof(rt_ray), hipMemcpyDeviceToHost, st));
+	if (hit_out) RT_HIP_CHECK(hipMemcpyAsync(hit_out, ctx->d_occ.p, (size_t)n, hipMemcpyDeviceToHost, st));
+	if (material_out) RT_HIP_CHECK(hipMemcpyAsync(material_out, ctx->d_keys.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	RT_CHECK(rt_collect_timing(ctx));
+	return RT_HIP_OK;
+}
+
+int rt_hip_occlude(rt_hip_ctx* ctx, const rt_ray* rays, int n, uint8_t* occluded_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (n < 0 || (n > 0 && (!rays || !occluded_out))) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	if (n == 0) return RT_HIP_OK;
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_records.reserve((size_t)n * sizeof(rt_ray)));
+	RT_CHECK(ctx->d_org.reserve((size_t)n * 12));
+	RT_CHECK(ctx->d_dir.reserve((size_t)n * 12));
+	RT_CHECK(ctx->d_occ.reserve((size_t)n));
+	rt_ray* d_rays = ctx->d_records.as<rt_ray>();
+	RT_HIP_CHECK(hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(rt_ray), hipMemcpyHostToDevice, st));
+	RT_CHECK(rt_launch_split_rays(ctx, d_rays, n, ctx->d_org.as<float>(), ctx->d_dir.as<float>()));
+	if (ctx->cfg.geometry == RT_HIP_SPHERES)
+		RT_CHECK(rt_launch_sphere_occlude(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), n, ctx->d_occ.as<uint8_t>()));
+	else
+		RT_CHECK(rt_launch_occlude_ref(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), n, ctx->d_occ.as<uint8_t>()));
+	RT_HIP_CHECK(hipMemcpyAsync(occluded_out, ctx->d_occ.p, (size_t)n, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	return RT_HIP_OK;
+}
+
+int rt_hip_sphere_colors(rt_hip_ctx* ctx, float* rgb_out, int max_spheres)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (!rgb_out) { rt_set_error("null output"); return RT_HIP_ERR_ARG; }
+	int n = std::min<int>(max_spheres, (int)ctx->spheres.size());
+	for (int i = 0; i < n; ++i)
+		for (int k = 0; k < 3; ++k) rgb_out[3 * i + k] = ctx->spheres[i].diffuse[k];
+	return n;
+}
+
+// ---- processRays ----------------------------------------------------------------------------
+int rt_hip_process_gbuffer_device(rt_hip_ctx* ctx, const float* d_positions_xyz, const float* d_normals_xyz, int count,
+                                  rt_ray* d_results, rt_result_offset* d_offsets, int* out_result_count,
+                                  int* out_material_count)
+{
+	RT_CHECK(check_ready(ctx));
+	if (count < 0 || !out_result_count || !out_material_count) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	*out_result_count = 0;
+	*out_material_count = 0;
+	ctx->last_count = 0;
+	if (count == 0) return RT_HIP_OK;  // defined behaviour where the reference has UB (rt_raytracer.cpp:538)
+	if (ctx->cfg.geometry != RT_HIP_TRIANGLES) { rt_set_error("processRays needs triangle geometry"); return RT_HIP_ERR_STATE; }
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_org.reserve((size_t)count * 12));
+	RT_CHECK(ctx->d_dir.reserve((size_t)count * 12));
+	RT_CHECK(ctx->d_hits.reserve((size_t)count * sizeof(Hit)));
+	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+	RT_CHECK(rt_launch_reflect_raygen(ctx, d_positions_xyz, d_normals_xyz, count, ctx->d_org.as<float>(), ctx->d_dir.as<float>()));
+	RT_CHECK(rt_launch_closest(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), count, ctx->d_hits.as<Hit>()));
+	RT_CHECK(rt_group_by_material(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), ctx->d_hits.as<Hit>(), count, d_results,
+	                              d_offsets, out_result_count, out_material_count));
+	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+	RT_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+	float ms = 0;
+	RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+	ctx->stats.frame_ms += ms;
+	ctx->stats.frames += 1;
+	ctx->last_count = count;
+	ctx->last_frame_rays = count;
+	RT_CHECK(rt_collect_timing(ctx));
+	return RT_HIP_OK;
+}
+
+int rt_hip_process_gbuffer(rt_hip_ctx* ctx, const float* positions_xyz, const float* normals_xyz, int count,
+                           const rt_ray** results, const rt_result_offset** result_offsets, int* out_result_count,
+                           int* out_material_count)
+{
+	RT_CHECK(check_ready(ctx));
+	if (count < 0 || !results || !result_offsets || !out_result_count || !out_material_count ||
+	    (count > 0 && (!positions_xyz || !normals_xyz))) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	hipStream_t st = ctx->stream;
+	size_t nmat = std::max<size_t>(ctx->materials.size(), 1);
+	RT_CHECK(rt_ensure_pinned(&ctx->h_records, &ctx->h_records_cap, std::max<size_t>((size_t)count, 1) * sizeof(rt_ray)));
+	RT_CHECK(rt_ensure_pinned(&ctx->h_offsets, &ctx->h_offsets_cap, nmat * sizeof(rt_result_offset)));
+	*results = (const rt_ray*)ctx->h_records;
+	*result_offsets = (const rt_result_offset*)ctx->h_offsets;
+	*out_result_count = 0;
+	*out_material_count = 0;
+	if (count == 0) { ctx->last_count = 0; return RT_HIP_OK; }
+	// G-buffer samples are uploaded once per frame with hipMemcpyAsync (north_star (1))
+	RT_CHECK(ctx->d_in_a.reserve((size_t)count * 12));
+	RT_CHECK(ctx->d_in_b.reserve((size_t)count * 12));
+	// d_in_a/d_in_b are reused by the grouping step, so stage the samples in dedicated buffers
+	RT_CHECK(ctx->d_accum.reserve((size_t)count * 24));
+	float* d_pos = ctx->d_accum.as<float>();
+	float* d_nrm = d_pos + (size_t)count * 3;
+	RT_HIP_CHECK(hipMemcpyAsync(d_pos, positions_xyz, (size_t)count * 12, hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipMemcpyAsync(d_nrm, normals_xyz, (size_t)count * 12, hipMemcpyHostToDevice, st));
+	RT_CHECK(ctx->d_records.reserve((size_t)count * sizeof(rt_ray)));
+	RT_CHECK(ctx->d_offsets.reserve(nmat * sizeof(rt_result_offset)));
+	int nres = 0, ngroups = 0;
+	RT_CHECK(rt_hip_process_gbuffer_device(ctx, d_pos, d_nrm, count, ctx->d_records.as<rt_ray>(),
+	                                       ctx->d_offsets.as<rt_result_offset>(), &nres, &ngroups));
+	if (nres > 0) RT_HIP_CHECK(hipMemcpyAsync(ctx->h_records, ctx->d_records.p, (size_t)nres * sizeof(rt_ray), hipMemcpyDeviceToHost, st));
+	if (ngroups > 0) RT_HIP_CHECK(hipMemcpyAsync(ctx->h_offsets, ctx->d_offsets.p, (size_t)ngroups * sizeof(rt_result_offset), hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	*out_result_count = nres;
+	*out_material_count = ngroups;
+	return RT_HIP_OK;
+}
+
+int rt_hip_last_hits(rt_hip_ctx* ctx, rt_hit* hits_out, float* directions_out, int count)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (count < 0 || count > ctx->last_count) { rt_set_error("count %d exceeds the last batch (%d)", count, ctx->last_count); return RT_HIP_ERR_ARG; }
+	if (count == 0) return RT_HIP_OK;
+	if (hits_out) RT_HIP_CHECK(hipMemcpy(hits_out, ctx->d_hits.p, (size_t)count * sizeof(rt_hit), hipMemcpyDeviceToHost));
+	if (directions_out) RT_HIP_CHECK(hipMemcpy(directions_out, ctx->d_dir.p, (size_t)count * 12, hipMemcpyDeviceToHost));
+	return RT_HIP_OK;
+}
+
+// ---- raw batch tracing -----------------------------------------------------------------------
+int rt_hip_trace_closest_device(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, rt_hit* d_hits)
+{
+	RT_CHECK(check_ready(ctx));
+	if (n < 0 || (n > 0 && (!d_org || !d_dir || !d_hits))) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	if (ctx->cfg.geometry != RT_HIP_TRIANGLES) { rt_set_error("triangle geometry required"); return RT_HIP_ERR_STATE; }
+	RT_CHECK(rt_launch_closest(ctx, d_org, d_dir, n, (Hit*)d_hits));
+	return RT_HIP_OK;
+}
+
+int rt_hip_trace_any_device(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occluded)
+{
+	RT_CHECK(check_ready(ctx));
+	if (n < 0 || (n > 0 && (!d_org || !d_dir || !d_occluded))) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	if (ctx->cfg.geometry != RT_HIP_TRIANGLES) { rt_set_error("triangle geometry required"); return RT_HIP_ERR_STATE; }
+	RT_CHECK(rt_launch_any(ctx, d_org, d_dir, n, d_occluded));
+	return RT_HIP_OK;
+}
+
+int rt_hip_trace_census_device(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, int any_hit,
+                               uint32_t* d_nodes_visited, uint32_t* d_tris_tested)
+{
+	RT_CHECK(check_ready(ctx));
+	if (n < 0 || (n > 0 && (!d_org || !d_dir || !d_nodes_visited || !d_tris_tested))) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	RT_CHECK(rt_launch_census(ctx, d_org, d_dir, n, any_hit, d_nodes_visited, d_tris_tested));
+	return RT_HIP_OK;
+}
+
+// ---- G-buffer hand-off -----------------------------------------------------------------------
+int rt_hip_gbuffer_select_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n, int interlace,
+                                 int phase, float* d_positions_out, float* d_normals_out, int* d_index_out,
+                                 int* out_count)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (n < 0 || !out_count || (n > 0 && (!d_nrm_rgba || !d_pos_rgb || !d_positions_out || !d_normals_out))) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	return rt_gbuffer_select(ctx, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_positions_out, d_normals_out, d_index_out, out_count);
+}
+
+int rt_hip_render_gbuffer_device(rt_hip_ctx* ctx, float fov, int width, int height, float* d_nrm_rgba, float* d_pos_rgb)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !d_nrm_rgba || !d_pos_rgb) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	return rt_render_gbuffer(ctx, fov, width, height, d_nrm_rgba, d_pos_rgb);
+}
+
+// ---- full frame --------------------------------------------------------------------------------
+int rt_hip_render_tiles_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
+                               int height, int tile, int rank, int nranks, uint8_t* d_rgba_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_rgba_out || tile <= 0 || nranks <= 0 ||
+	    rank < 0 || rank >= nranks) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	return rt_render_frame(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, tile, rank, nranks, d_rgba_out);
+}
+
+int rt_hip_render_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
+                               int height, uint8_t* d_rgba_out)
+{
+	return rt_hip_render_tiles_device(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, 64, 0, 1, d_rgba_out);
+}
+
+int rt_hip_render_frame(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float* gbuf_nrm_rgba, int width, int height,
+                        uint8_t* rgba_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !gbuf_pos_rgb || !gbuf_nrm_rgba || !rgba_out) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	hipStream_t st = ctx->stream;
+	size_t npix = (size_t)width * height;
+	RT_CHECK(ctx->d_in_a.reserve(npix * 12));
+	RT_CHECK(ctx->d_in_b.reserve(npix * 16));
+	RT_CHECK(ctx->d_offsets.reserve(npix * 4));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_in_a.p, gbuf_pos_rgb, npix * 12, hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_in_b.p, gbuf_nrm_rgba, npix * 16, hipMemcpyHostToDevice, st));
+	RT_CHECK(rt_render_frame(ctx, ctx->d_in_a.as<float>(), ctx->d_in_b.as<float>(), width, height, 64, 0, 1, ctx->d_offsets.as<uint8_t>()));
+	RT_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_offsets.p, npix * 4, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	return RT_HIP_OK;
+}
+
+int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx) { return ctx ? ctx->last_frame_rays : 0; }
+
+// ---- photon map ----------------------------------------------------------------------------------
+int rt_hip_photon_emit_device(rt_hip_ctx* ctx, int photons_per_light, int64_t first, int64_t count, float* d_photons_out,
+                              int64_t capacity, int64_t* out_stored)
+{
+	RT_CHECK(check_ready(ctx));
+	if (photons_per_light <= 0 || first < 0 || count < 0 || !d_photons_out || capacity < count || !out_stored) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	return rt_photon_emit(ctx, photons_per_light, first, count, d_photons_out, capacity, out_stored);
+}
+
+int rt_hip_photon_set_device(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (n < 0 || (n > 0 && !d_photons)) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	return rt_photon_build_grid(ctx, d_photons, n);
+}
+
+int rt_hip_photon_set(rt_hip_ctx* ctx, const float* photons, int64_t n)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (n < 0 || (n > 0 && !photons)) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	RT_CHECK(ctx->d_photon_tmp.reserve(std::max<size_t>((size_t)n, 1) * 36));
+	if (n > 0) RT_HIP_CHECK(hipMemcpy(ctx->d_photon_tmp.p, photons, (size_t)n * 36, hipMemcpyHostToDevice));
+	return rt_photon_build_grid(ctx, ctx->d_photon_tmp.as<float>(), n);
+}
+
+int rt_hip_radiance_estimate_device(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int npts, int count,
+                                    float radius, float* d_rgb_out)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (npts < 0 || count <= 0 || !(radius > 0.0f) || (npts > 0 && (!d_pos || !d_nrm || !d_rgb_out))) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	return rt_photon_gather(ctx, d_pos, d_nrm, npts, count, radius, d_rgb_out);
+}
+
+int rt_hip_radiance_estimate(rt_hip_ctx* ctx, const float* pos, const float* nrm, int npts, int count, float radius,
+                             float* rgb_out)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (npts < 0 || (npts > 0 && (!pos || !nrm || !rgb_out))) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	if (npts == 0) return RT_HIP_OK;
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_org.reserve((size_t)npts * 12));
+	RT_CHECK(ctx->d_dir.reserve((size_t)npts * 12));
+	RT_CHECK(ctx->d_accum.reserve((size_t)npts * 12));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_org.p, pos, (size_t)npts * 12, hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_dir.p, nrm, (size_t)npts * 12, hipMemcpyHostToDevice, st));
+	RT_CHECK(rt_hip_radiance_estimate_device(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), npts, count, radius,
+	                                         ctx->d_accum.as<float>()));
+	RT_HIP_CHECK(hipMemcpyAsync(rgb_out, ctx->d_accum.p, (size_t)npts * 12, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	return RT_HIP_OK;
+}
+
+// ---- introspection -------------------------------------------------------------------------------
+int rt_hip_get_stats(rt_hip_ctx* ctx, rt_hip_stats* out)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (!out) { rt_set_error("null output"); return RT_HIP_ERR_ARG; }
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	RT_CHECK(rt_collect_timing(ctx));
+	*out = ctx->stats;
+	return RT_HIP_OK;
+}
+
+int rt_hip_reset_stats(rt_hip_ctx* ctx)
+{
+	RT_CHECK(check_ctx(ctx));
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	RT_CHECK(rt_collect_timing(ctx));
+	double build = ctx->stats.build_ms;
+	memset(&ctx->stats, 0, sizeof(ctx->stats));
+	ctx->stats.build_ms = build;
+	ctx->stats.num_tris = ctx->num_tris;
+	ctx->stats.num_nodes = ctx->num_nodes;
+	ctx->stats.bvh_depth = ctx->bvh_depth;
+	return RT_HIP_OK;
+}
+
+int rt_hip_sync(rt_hip_ctx* ctx)
+{
+	RT_CHECK(check_ctx(ctx));
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return RT_HIP_OK;
+}
+
+void* rt_hip_stream(rt_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rt_hip_get_bvh(rt_hip_ctx* ctx, float* nodes_out, int64_t max_nodes, uint32_t* leaf_prims_out, int64_t max_tris)
+{
+	RT_CHECK(check_ready(ctx));
+	if (!ctx->use_bvh) { rt_set_error("no LBVH was built for this scene"); return RT_HIP_ERR_STATE; }
+	if (max_nodes < ctx->num_nodes || max_tris < ctx->num_tris) { rt_set_error("output arrays too small"); return RT_HIP_ERR_ARG; }
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	if (nodes_out) RT_HIP_CHECK(hipMemcpy(nodes_out, ctx->d_nodes.p, (size_t)ctx->num_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+	if (leaf_prims_out) {
+		std::vector<TriIsect> t((size_t)ctx->num_tris);
+		RT_HIP_CHECK(hipMemcpy(t.data(), ctx->d_tri_isect.p, t.size() * sizeof(TriIsect), hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < t.size(); ++i) memcpy(&leaf_prims_out[i], &t[i].a.w, 4);
+	}
+	return RT_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// raytracer_amd/csrc/rt_ctx.h -- host-side context and the kernel launch interface between the
+// translation units of librt_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_dev.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void rt_set_error(const char* fmt, ...);
+#define RT_HIP_CHECK(expr)                                                                        \
+	do {                                                                                          \
+		hipError_t e__ = (expr);                                                                  \
+		if (e__ != hipSuccess) {                                                                  \
+			rt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+			return RT_HIP_ERR_HIP;                                                                \
+		}                                                                                         \
+	} while (0)
+#define RT_CHECK(expr)                    \
+	do {                                  \
+		int s__ = (expr);                 \
+		if (s__ != RT_HIP_OK) return s__; \
+	} while (0)
+
+// Growable device buffer (never shrinks; the frame loop allocates nothing in steady state).
+struct DevBuf {
+	void* p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t bytes);
+	void release();
+	template <typename T> T* as() const { return (T*)p; }
+};
+
+struct HostMesh {
+	std::vector<float> verts, normals, texcoords;
+	std::vector<uint32_t> faces;
+	float model[16];
+	int material;
+	float position[3];
+	uint32_t first_tri;  // global id of face 0
+	size_t vert_offset;  // into the concatenated device vertex arrays
+};
+
+struct HostSphere {
+	float c[3];
+	float r;
+	float diffuse[3];
+};
+
+// Device scene views handed to kernels.
+struct SceneView {
+	const BvhNode* nodes;
+	const TriIsect* tris;     // leaf order
+	const TriPos* tri_pos;    // original id order
+	const TriAttr* tri_attr;  // original id order
+	const SphereRec* spheres;
+	const MaterialRec* materials;
+	const LightRec* lights;
+	int num_tris;
+	int num_spheres;
+	int num_materials;
+	int num_lights;
+	int use_bvh;      // 0: brute force over `tris`
+	int stack_depth;  // required traversal stack entries (BVH depth + 1)
+	TraceParams tp;
+};
+
+struct rt_hip_ctx {
+	rt_hip_config cfg;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;  // pending (profile mode)
+	size_t trace_events_used = 0;
+
+	std::vector<HostMesh> meshes;
+	std::vector<HostSphere> spheres;
+	std::vector<rt_material> materials;
+	std::vector<rt_light> lights;
+	bool scene_dirty = true;
+	bool sphere_rng_seeded = false;
+
+	// geometry in HBM
+	DevBuf d_verts, d_normals, d_texcoords, d_faces, d_mesh_of_tri, d_mesh_xf;  // inputs of the soup kernel
+	DevBuf d_tri_pos, d_tri_attr, d_tri_isect, d_tri_box, d_nodes, d_spheres, d_materials, d_lights;
+	DevBuf d_morton, d_morton_tmp, d_order, d_order_tmp, d_hist, d_flags, d_parent_leaf, d_bounds, d_misc;
+	int num_tris = 0, num_nodes = 0, bvh_depth = 0, use_bvh = 0;
+	float bounds[6];
+
+	// per-call scratch in HBM
+	DevBuf d_org, d_dir, d_hits, d_occ, d_in_a, d_in_b, d_records, d_offsets, d_keys, d_rank, d_counts;
+	DevBuf d_nodes_a, d_nodes_b, d_rays_q, d_ray_parent, d_accum, d_qcount, d_gate;
+	// pinned host staging
+	void* h_records = nullptr; size_t h_records_cap = 0;
+	void* h_offsets = nullptr; size_t h_offsets_cap = 0;
+	void* h_small = nullptr;   // 4 KiB pinned scratch for counters
+
+	// photon map
+	DevBuf d_photons, d_photon_cell, d_photon_sorted, d_cell_start, d_photon_tmp;
+	int64_t num_photons = 0;
+	float photon_cell = 1.0f;
+	float photon_grid_min[3];
+	int photon_grid_dim[3];
+
+	int last_count = 0;
+	int64_t last_frame_rays = 0;
+	rt_hip_stats stats;
+};
+
+SceneView rt_scene_view(const rt_hip_ctx* ctx);
+int rt_begin_trace_timing(rt_hip_ctx* ctx);
+int rt_end_trace_timing(rt_hip_ctx* ctx);
+int rt_collect_timing(rt_hip_ctx* ctx);
+int rt_ensure_pinned(void** p, size_t* cap, size_t bytes);
+
+// ---- k_geometry.hip ------------------------------------------------------------------------------
+int rt_build_geometry(rt_hip_ctx* ctx);  // soup + (optional) LBVH, all on ctx->stream
+
+// ---- k_lbvh.hip ----------------------------------------------------------------------------------
+int rt_build_lbvh(rt_hip_ctx* ctx);
+
+// ---- k_trace.hip ---------------------------------------------------------------------------------
+int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, Hit* d_hits);
+int rt_launch_any(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ);
+int rt_launch_occlude_ref(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ);
+int rt_launch_census(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, int any_hit, uint32_t* d_nv,
+                     uint32_t* d_nt);
+int rt_launch_sphere_intersect(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, int* d_index,
+                               float* d_pos, float* d_nrm);
+int rt_launch_sphere_occlude(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ);
+
+// ---- k_frame.hip ---------------------------------------------------------------------------------
+int rt_launch_split_rays(rt_hip_ctx* ctx, const rt_ray* d_rays, int n, float* d_org, float* d_dir);
+int rt_launch_reflect_raygen(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int n, float* d_org,
+                             float* d_dir);
+int rt_launch_fill_records(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, const Hit* d_hits, int n,
+                           rt_ray* d_rays_inout, uint8_t* d_hit_flag, uint32_t* d_material);
+int rt_group_by_material(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, const Hit* d_hits, int n,
+                         rt_ray* d_records, rt_result_offset* d_offsets, int* out_results, int* out_groups);
+int rt_gbuffer_select(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n, int interlace,
+                      int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* out_count);
+int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb);
+int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
+                    int rank, int nranks, uint8_t* d_rgba);
+
+// ---- k_photon.hip --------------------------------------------------------------------------------
+int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count, float* d_out, int64_t capacity,
+                   int64_t* out_stored);
+int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n);
+int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int npts, int count, float radius,
+                     float* d_rgb);
+
+// ---- shared device-scan / multisplit helpers (k_sort.hip) -----------------------------------------
+// Stable counting-sort pass on an 8-bit digit: out_rank[i] = destination of element i.
+int rt_multisplit256(rt_hip_ctx* ctx, const uint32_t* d_digit, int n, uint32_t* d_dest, uint32_t* d_bucket_totals);
+int rt_radix_sort_pairs64(rt_hip_ctx* ctx, uint64_t* d_keys, uint64_t* d_keys_tmp, uint32_t* d_vals,
+                          uint32_t* d_vals_tmp, int n, int key_bits);

@@ -1,0 +1,211 @@
+// raytracer_amd/csrc/rt_dev.h -- device-side types, exact-arithmetic helpers and the traversal
+// core shared by every kernel file (gfx950 only; compiled with -ffp-contract=off so that the
+// intersection arithmetic is the reference's operation-for-operation; FMA is used only where it
+// is written out as __builtin_fmaf, i.e. in the conservative box tests).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_MISS 0xFFFFFFFFu
+#define RT_WAVE 64
+
+struct f3 {
+	float x, y, z;
+};
+
+__host__ __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__host__ __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__host__ __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__host__ __device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__host__ __device__ __forceinline__ f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+// Reduction order of Eigen's 3-vector dot (Redux.h:98-101): a0*b0 + (a1*b1 + a2*b2).
+__host__ __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__host__ __device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+	return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// IEEE-correct square root: HIP's __fsqrt_rn lowers to the *native* (approximate) sqrt unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined; sqrtf under
+// -fhip-fp32-correctly-rounded-divide-sqrt is correctly rounded, which parity needs.
+__device__ __forceinline__ float rt_sqrtf(float x) { return __builtin_sqrtf(x); }
+// Eigen's v / s multiplies by the reciprocal (Functors.h:455-456); both IEEE-rounded.
+__device__ __forceinline__ f3 div3(f3 a, float s) { float inv = 1.0f / s; return a * inv; }
+__device__ __forceinline__ float norm3(f3 a) { return rt_sqrtf(dot3(a, a)); }
+__device__ __forceinline__ f3 normalized3(f3 a) { return div3(a, norm3(a)); }
+// (1-u-v)*a + u*b + v*c evaluated left to right (rt_raytracer.cpp:520, rt_accel_array.cpp:127)
+__device__ __forceinline__ f3 bary3(float u, float v, f3 a, f3 b, f3 c)
+{
+	float w = (1.0f - u - v);
+	return (a * w + b * u) + c * v;
+}
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+// ---- geometry records in HBM ---------------------------------------------------------------
+// 64-byte BVH node: both children's boxes live in the parent, one aligned 64-B fetch per visit.
+//   q0 = (l.min.x, l.min.y, l.min.z, l.max.x)
+//   q1 = (l.max.y, l.max.z, r.min.x, r.min.y)
+//   q2 = (r.min.z, r.max.x, r.max.y, r.max.z)
+//   q3 = (bits left, bits right, bits parent, 0)   child >= 0: internal node, child < 0: ~leaf slot
+struct __attribute__((aligned(64))) BvhNode {
+	float4 q0, q1, q2;
+	int left, right, parent, pad;
+};
+static_assert(sizeof(BvhNode) == 64, "BVH node is one 64-byte line");
+
+// 48-byte intersection record in leaf (Morton) order: the M-T operands, nothing else.
+//   a = (v0.xyz, bits prim id), b = (e1.xyz, 0), c = (e2.xyz, 0)
+struct __attribute__((aligned(16))) TriIsect {
+	float4 a, b, c;
+};
+static_assert(sizeof(TriIsect) == 48, "triangle fetch is 48 bytes");
+
+// Per-primitive (original id order) attributes for hit-record construction.
+//   p0 = (v0.xyz, bits material), p1 = (v1.xyz, 0), p2 = (v2.xyz, 0)            48 B
+//   n0.xyz n1.xyz n2.xyz t0.xy t1.xy t2.xy pad                                    64 B
+struct __attribute__((aligned(16))) TriPos {
+	float4 p0, p1, p2;
+};
+struct __attribute__((aligned(16))) TriAttr {
+	float n0[3], n1[3], n2[3];
+	float t0[2], t1[2], t2[2];
+	float pad;
+};
+static_assert(sizeof(TriAttr) == 64, "attribute record is 64 bytes");
+
+struct SphereRec {
+	float cx, cy, cz, r;
+};
+
+struct MaterialRec {  // device copy of rt_material without the texture slot
+	float diffuse[3];
+	float specular[3];
+	float shininess, reflectivity, alpha, ior;
+	float pad[2];
+};
+static_assert(sizeof(MaterialRec) == 48, "material record");
+
+struct LightRec {
+	float position[3];
+	float color[3];
+	float energy;
+	float pad;
+};
+
+struct Hit {
+	uint32_t prim;
+	float t, u, v;
+};
+
+struct TraceParams {
+	float eps_det, eps_t, t_max;
+};
+
+// ---- Moeller-Trumbore with backface culling, the reference's operation order ----------------
+// rt_raytracer.cpp:326-368 / rt_accel_array.cpp:87-121.  Returns true and updates (t,u,v) when
+// the triangle is hit in front of the current best; `prim` breaks exact ties towards the lower
+// id (brute force keeps the lowest index by construction, rt_accel_array.cpp:116).
+__device__ __forceinline__ bool mt_closest(f3 O, f3 D, f3 v0, f3 e1, f3 e2, uint32_t prim, const TraceParams& tp,
+                                           Hit& best)
+{
+	f3 P = cross3(D, e2);
+	float det = dot3(P, e1);
+	if (det < tp.eps_det) return false;
+	f3 T = O - v0;
+	float u = dot3(T, P);
+	if (u < 0.0f || u > det) return false;
+	f3 Q = cross3(T, e1);
+	float v = dot3(D, Q);
+	if (v < 0.0f || u + v > det) return false;
+	float t = dot3(e2, Q);
+	float inv_det = 1.0f / det;  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+	t *= inv_det;
+	u *= inv_det;
+	v *= inv_det;
+	if (t < tp.eps_t) return false;
+	if (t < best.t || (t == best.t && prim < best.prim)) {
+		best.t = t; best.u = u; best.v = v; best.prim = prim;
+		return true;
+	}
+	return false;
+}
+
+// Any-hit with intersect's acceptance tests (eps_det, eps_t, t < t_max).
+__device__ __forceinline__ bool mt_any(f3 O, f3 D, f3 v0, f3 e1, f3 e2, const TraceParams& tp)
+{
+	f3 P = cross3(D, e2);
+	float det = dot3(P, e1);
+	if (det < tp.eps_det) return false;
+	f3 T = O - v0;
+	float u = dot3(T, P);
+	if (u < 0.0f || u > det) return false;
+	f3 Q = cross3(T, e1);
+	float v = dot3(D, Q);
+	if (v < 0.0f || u + v > det) return false;
+	float t = dot3(e2, Q);
+	float inv_det = 1.0f / det;
+	t *= inv_det;
+	if (t < tp.eps_t) return false;
+	return t < tp.t_max;
+}
+
+// AccelArray::occlude (rt_accel_array.cpp:45-73): t is computed and never tested.
+__device__ __forceinline__ bool mt_occlude_ref(f3 O, f3 D, f3 v0, f3 e1, f3 e2, float eps_det)
+{
+	f3 P = cross3(D, e2);
+	float det = dot3(P, e1);
+	if (det < eps_det) return false;
+	f3 T = O - v0;
+	f3 Q = cross3(T, e1);
+	float inv = 1.0f / det;
+	float uu = dot3(P, T) * inv;
+	float vv = dot3(Q, D) * inv;
+	return uu >= 0.0f && vv >= 0.0f && uu + vv <= 1.0f && 1.0f >= uu;
+}
+
+// ---- conservative ray/box (slab) test ------------------------------------------------------
+// Not the reference's Woo test (rt_raytracer.cpp:194-248, which ignores ray.t and only culls):
+// a slab test on boxes that were padded at build time.  (b - o) * inv carries <= 2 ulp of
+// relative error, so the interval is widened by 4 ulp on each side and the test never rejects a
+// box whose triangle the exact M-T test would accept.
+struct RayPre {
+	f3 o;
+	f3 inv;  // 1/d with |d| < 1e-20 replaced by +-1e-20 before inversion (no inf, no 0*inf NaN)
+};
+
+__device__ __forceinline__ float safe_rcp(float d)
+{
+	float s = (fabsf(d) < 1e-20f) ? copysignf(1e-20f, d) : d;
+	return 1.0f / s;
+}
+
+__device__ __forceinline__ RayPre ray_pre(f3 o, f3 d)
+{
+	RayPre r;
+	r.o = o;
+	r.inv = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+	return r;
+}
+
+// Hit iff the widened slab interval intersects [0, tlimit]; entry distance in `tnear`.
+__device__ __forceinline__ bool slab(const RayPre& r, float mnx, float mny, float mnz, float mxx, float mxy,
+                                     float mxz, float tlimit, float& tnear)
+{
+	float x0 = (mnx - r.o.x) * r.inv.x, x1 = (mxx - r.o.x) * r.inv.x;
+	float y0 = (mny - r.o.y) * r.inv.y, y1 = (mxy - r.o.y) * r.inv.y;
+	float z0 = (mnz - r.o.z) * r.inv.z, z1 = (mxz - r.o.z) * r.inv.z;
+	float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+	float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+	tn *= 0.9999995f;
+	tf *= 1.0000005f;
+	tnear = tn;
+	return tn <= fminf(tf, tlimit);
+}
+
+// ---- wave helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t lanemask_lt()
+{
+	return (1ull << lane_id()) - 1ull;
+}

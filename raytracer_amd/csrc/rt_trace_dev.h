@@ -1,0 +1,132 @@
+// raytracer_amd/csrc/rt_trace_dev.h -- the inlined traversal core (used by the batch trace
+// kernels, the shading kernels and the photon emitter) and the sphere tests.
+#pragma once
+
+#include "rt_ctx.h"
+
+// Traverse the LBVH for one ray.  `stack` points at this lane's column of an LDS array laid out
+// [depth][block_threads] (so that every ds_read/ds_write of a wave touches 64 consecutive dwords
+// -> conflict free), `stride` = threads per block.
+//   ANY = false: closest hit into `best` (prim = RT_MISS / t = +inf on a miss); returns hit?
+//   ANY = true : first accepted hit terminates; returns occluded?
+template <bool ANY, bool CENSUS>
+__device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& best, int* stack, int stride,
+                                          uint32_t& cnt_nodes, uint32_t& cnt_tris)
+{
+	best.prim = RT_MISS;
+	best.t = sv.tp.t_max;
+	best.u = 0.0f;
+	best.v = 0.0f;
+	bool found = false;
+	if (sv.num_tris > 0) {
+		const RayPre rp = ray_pre(O, D);
+		// num_tris == 1: no internal node; the root "node" is leaf slot 0.
+		int cur = (sv.num_tris == 1) ? ~0 : 0;
+		int sp = 0;
+		const int SENTINEL = 0x7fffffff;
+		while (cur != SENTINEL) {
+			if (cur >= 0) {
+				const float4* np = (const float4*)(sv.nodes + cur);
+				float4 q0 = np[0], q1 = np[1], q2 = np[2];
+				int4 q3 = *((const int4*)(np + 3));
+				if (CENSUS) ++cnt_nodes;
+				float tl, tr;
+				float lim = ANY ? sv.tp.t_max : best.t;
+				bool hl = slab(rp, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, lim, tl);
+				bool hr = slab(rp, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, lim, tr);
+				if (hl && hr) {
+					bool left_first = tl <= tr;
+					int nearc = left_first ? q3.x : q3.y;
+					int farc = left_first ? q3.y : q3.x;
+					stack[sp * stride] = farc;
+					++sp;
+					cur = nearc;
+				} else if (hl) {
+					cur = q3.x;
+				} else if (hr) {
+					cur = q3.y;
+				} else {
+					if (sp == 0) cur = SENTINEL;
+					else { --sp; cur = stack[sp * stride]; }
+				}
+			} else {
+				const TriIsect* tp = sv.tris + (~cur);
+				float4 a = tp->a, b = tp->b, c = tp->c;
+				if (CENSUS) ++cnt_tris;
+				f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+				if (ANY) {
+					if (mt_any(O, D, v0, e1, e2, sv.tp)) { found = true; break; }
+				} else {
+					if (mt_closest(O, D, v0, e1, e2, __float_as_uint(a.w), sv.tp, best)) found = true;
+				}
+				if (sp == 0) cur = SENTINEL;
+				else { --sp; cur = stack[sp * stride]; }
+			}
+		}
+	}
+	if (!ANY && best.prim == RT_MISS) best.t = __builtin_inff();
+	return found;
+}
+
+// Brute-force loop over sv.tris with the same contract (used when the scene has no BVH).
+template <bool ANY>
+__device__ __forceinline__ bool brute_trace(const SceneView& sv, f3 O, f3 D, Hit& best)
+{
+	best.prim = RT_MISS;
+	best.t = sv.tp.t_max;
+	best.u = 0.0f;
+	best.v = 0.0f;
+	bool found = false;
+	for (int k = 0; k < sv.num_tris; ++k) {
+		float4 a = sv.tris[k].a, b = sv.tris[k].b, c = sv.tris[k].c;
+		f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+		if (ANY) {
+			if (mt_any(O, D, v0, e1, e2, sv.tp)) { found = true; break; }
+		} else {
+			if (mt_closest(O, D, v0, e1, e2, __float_as_uint(a.w), sv.tp, best)) found = true;
+		}
+	}
+	if (!ANY && best.prim == RT_MISS) best.t = __builtin_inff();
+	return found;
+}
+
+template <bool ANY>
+__device__ __forceinline__ bool scene_trace(const SceneView& sv, f3 O, f3 D, Hit& best, int* stack, int stride)
+{
+	uint32_t a = 0, b = 0;
+	if (sv.use_bvh) return bvh_trace<ANY, false>(sv, O, D, best, stack, stride, a, b);
+	return brute_trace<ANY>(sv, O, D, best);
+}
+
+// ---- spheres (rt_accel_spheres.cpp) -----------------------------------------------------------
+// One sphere of AccelSpheres::intersect's loop body (:66-100).  Ro is passed explicitly; the
+// reference passes the DIRECTION as Ro (:68) and callers reproduce that.
+__device__ __forceinline__ bool sphere_test_ref(const SphereRec& s, f3 Ro, f3 Rd, f3& X, f3& N)
+{
+	f3 c = mk3(s.cx, s.cy, s.cz);
+	f3 oc = Ro - c;
+	float b = dot3(Rd * 2.0f, oc);
+	float cc = dot3(oc, oc) - s.r * s.r;
+	float disc = (b * b - 4.0f * cc);
+	if (disc < 0.0f) return false;
+	disc = rt_sqrtf(disc);
+	float t0 = (-b - disc) * 0.5f;
+	float t1 = (-b + disc) * 0.5f;
+	if (t0 < 0.0f && t1 > 0.0f) return false;  // inside the sphere
+	t0 = fminf(t0, t1);
+	if (t0 <= 0.0f) return false;
+	X = Ro + Rd * t0;
+	float distance = dot3(X, X);
+	if (!(distance < 1000000.0f)) return false;
+	N = div3(X - c, s.r);
+	return true;
+}
+
+__device__ __forceinline__ bool sphere_occlude_ref(const SphereRec& s, f3 Ro, f3 Rd)
+{
+	f3 c = mk3(s.cx, s.cy, s.cz);
+	f3 oc = Ro - c;
+	float b = dot3(Rd * 2.0f, oc);
+	float cc = dot3(oc, oc) - s.r * s.r;
+	return (b * b - 4.0f * cc) > 0.0f;
+}

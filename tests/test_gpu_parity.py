@@ -1,0 +1,230 @@
+"""GPU parity: the HIP path (through the C ABI of include/rt_hip.h) against the CPU oracle on
+the same seeded inputs.  Bar: ids bit-exact, t/u/v bit-exact (the kernels run the reference's
+operation order with FMA contraction off), hit records bit-exact for identity / translation model
+matrices and within 1e-5 for general ones (normal matrix inverse)."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+MISS = 0xFFFFFFFF
+
+
+def _rays_for(scene, orc, w=96, h=72, seed=0):
+    d = orc.camera_rays(scene.fov, w, h)
+    rng = np.random.RandomState(seed)
+    o = rng.uniform(-1, 1, (d.shape[0], 3)).astype(np.float32)
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+def _gbuf_samples(orc, w, h):
+    nr, po = orc.software_gbuffer(w, h)
+    return orc.gbuffer_select(nr, po)
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracer_amd
+    return raytracer_amd
+
+
+@pytest.mark.parametrize("scene_fn", [scenes.cornell, lambda: scenes.atrium(2048)], ids=["cornell", "atrium2k"])
+@pytest.mark.parametrize("accel", [1, 2], ids=["brute", "lbvh"])
+def test_array_intersect(rt, oracle_cls, scene_fn, accel):
+    sc = scene_fn()
+    orc = oracle_cls(sc)
+    rays = _rays_for(sc, orc)
+    a = orc.array_intersect(rays)
+    g = rt.RtHip(sc, semantics="array", accel=accel)
+    b = g.intersect(rays)
+    assert a["hit"].sum() > 100
+    np.testing.assert_array_equal(a["hit"], b["hit"])
+    np.testing.assert_array_equal(a["material"], b["material"])
+    hit = a["hit"] > 0
+    np.testing.assert_array_equal(a["index"][hit], b["hits"]["prim"][hit].astype(np.int64))
+    assert_bits_equal(a["t"][hit], b["hits"]["t"][hit], "t")
+    for f in ("origin", "direction", "position", "normal", "texcoord"):
+        assert_bits_equal(a["records"][f], b["records"][f], f)
+    g.close()
+
+
+def test_array_occlude(rt, oracle_cls):
+    sc = scenes.atrium(2048)
+    orc = oracle_cls(sc)
+    rays = _rays_for(sc, orc, 64, 48, seed=3)
+    a = orc.array_occlude(rays)
+    g = rt.RtHip(sc, semantics="array")
+    b = g.occlude(rays)
+    assert 0 < a.sum() < a.size
+    np.testing.assert_array_equal(a, b)
+    g.close()
+
+
+def _check_process(sc, orc, g, w, h, min_match=0.999):
+    """DACRT (oracle.process_rays, pinned bit for bit to the compiled reference) keeps the first
+    triangle in ITS traversal order on an exact-t tie; the HIP path keeps the lowest id, as
+    rt_accel_array.cpp:116 does.  So: hit/miss and t must agree on every ray, ids may differ only
+    where t is bit-identical (shared-edge ties), and against the exhaustive lowest-id oracle
+    (orc.soup_closest) ids, t, u, v must all be bit-exact."""
+    pos, nrm, _ = _gbuf_samples(orc, w, h)
+    a = orc.process_rays(pos, nrm)
+    b = g.process_rays(pos, nrm)
+    assert_bits_equal(a["dir"], b["dir"], "dir")
+    hit_a = a["tidx"] != MISS
+    assert hit_a.sum() > 100
+    np.testing.assert_array_equal(hit_a, b["tidx"] != MISS)
+    same = a["tidx"] == b["tidx"]
+    assert same.mean() >= min_match, same.mean()
+    assert_bits_equal(a["t"][hit_a], b["t"][hit_a], "t")          # t is equal even on ties
+    c = orc.soup_closest(pos, a["dir"])
+    np.testing.assert_array_equal(c["tidx"], b["tidx"])
+    assert_bits_equal(c["t"], b["t"], "t vs exhaustive")
+    assert_bits_equal(c["u"][hit_a], b["u"][hit_a], "u vs exhaustive")
+    assert_bits_equal(c["v"][hit_a], b["v"][hit_a], "v vs exhaustive")
+    both = hit_a & same
+    assert_bits_equal(a["u"][both], b["u"][both], "u")
+    assert_bits_equal(a["v"][both], b["v"][both], "v")
+    return a, b, same
+
+
+def _tri_material(sc):
+    return np.concatenate([np.full(m.faces.shape[0], m.material, np.int32) for m in sc.meshes])
+
+
+def _check_groups(sc, a, b, same):
+    """processRays' output contract (rt_raytracer.cpp:510-539): hits only, grouped by material,
+    cumulative end offsets, ascending input index inside a group."""
+    tm = _tri_material(sc)
+    hit = b["tidx"] != MISS
+    mats = tm[b["tidx"][hit]]
+    idx = np.nonzero(hit)[0]
+    order = np.lexsort((idx, mats))                     # by material, then input index
+    present = np.unique(mats)
+    np.testing.assert_array_equal(b["offset_material"], present)
+    np.testing.assert_array_equal(b["offset_end"], np.cumsum([np.sum(mats == m) for m in present]))
+    assert len(b["records"]) == hit.sum()
+    assert_bits_equal(b["records"]["direction"], b["dir"][idx[order]], "record order")
+    if same.all():                                      # no tie in this batch: everything is bit-exact
+        np.testing.assert_array_equal(a["offset_material"], b["offset_material"])
+        np.testing.assert_array_equal(a["offset_end"], b["offset_end"])
+        for f in ("origin", "direction", "position", "normal", "texcoord"):
+            assert_bits_equal(a["records"][f], b["records"][f], f)
+    else:                                               # compare the records of the rays that agree
+        ia = np.nonzero(a["tidx"] != MISS)[0]
+        oa = ia[np.lexsort((ia, tm[a["tidx"][ia]]))]
+        ob = idx[order]
+        pa = {int(r): k for k, r in enumerate(oa)}
+        sel_b = np.array([k for k, r in enumerate(ob) if same[r]])
+        sel_a = np.array([pa[int(ob[k])] for k in sel_b])
+        for f in ("origin", "direction", "position", "normal", "texcoord"):
+            assert_bits_equal(a["records"][f][sel_a], b["records"][f][sel_b], f)
+
+
+@pytest.mark.parametrize("accel", [1, 2], ids=["brute", "lbvh"])
+def test_process_rays_cornell(rt, oracle_cls, accel):
+    sc = scenes.cornell()
+    orc = oracle_cls(sc)
+    g = rt.RtHip(sc, accel=accel)
+    a, b, same = _check_process(sc, orc, g, 160, 120)
+    _check_groups(sc, a, b, same)
+    g.close()
+
+
+def test_process_rays_atrium_lbvh(rt, oracle_cls):
+    sc = scenes.atrium(8192)
+    orc = oracle_cls(sc)
+    g = rt.RtHip(sc, accel=2)
+    a, b, same = _check_process(sc, orc, g, 160, 120)
+    _check_groups(sc, a, b, same)
+    st = g.stats()
+    assert st["num_nodes"] == st["num_tris"] - 1
+    g.close()
+
+
+def test_process_rays_transformed(rt, oracle_cls):
+    sc = scenes.with_transforms(scenes.atrium(2048))
+    orc = oracle_cls(sc)
+    g = rt.RtHip(sc, accel=2)
+    a, b, same = _check_process(sc, orc, g, 128, 96)
+    _check_groups(sc, a, b, same)  # normals too: both sides use the same double-precision inverse
+    g.close()
+
+
+def test_process_rays_edge_cases(rt, oracle_cls):
+    sc = scenes.cornell()
+    g = rt.RtHip(sc)
+    # empty batch: defined (the reference has UB here, rt_raytracer.cpp:538)
+    r = g.process_rays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert len(r["records"]) == 0 and len(r["offset_end"]) == 0
+    # all rays miss: positions far outside looking away
+    pos = np.tile(np.array([[0, 0, 100.0]], np.float32), (77, 1))
+    nrm = np.tile(np.array([[1.0, 0, 0]], np.float32), (77, 1))  # P.N = 0: the ray leaves along +z
+    r = g.process_rays(pos, nrm)
+    assert len(r["records"]) == 0 and (r["tidx"] == MISS).all()
+    # ragged: not a multiple of the wave size
+    orc = oracle_cls(sc)
+    p, n, _ = _gbuf_samples(orc, 37, 29)
+    a = orc.process_rays(p[:1001], n[:1001])
+    b = g.process_rays(p[:1001], n[:1001])
+    np.testing.assert_array_equal(a["tidx"], b["tidx"])
+    np.testing.assert_array_equal(a["offset_end"], b["offset_end"])
+    g.close()
+
+
+def test_bvh_structure(rt):
+    sc = scenes.atrium(8192)
+    g = rt.RtHip(sc, accel=2)
+    nodes, prims = g.get_bvh()
+    n = prims.shape[0]
+    assert sorted(prims.tolist()) == list(range(n))
+    left = nodes[:, 12].view(np.int32)
+    right = nodes[:, 13].view(np.int32)
+    parent = nodes[:, 14].view(np.int32)
+    assert parent[0] == -1
+    # every internal node's stored child box must contain that child's own children boxes
+    lmin, lmax = nodes[:, 0:3], nodes[:, 3:6]
+    rmin, rmax = nodes[:, 6:9], nodes[:, 9:12]
+    for child, cmin, cmax in ((left, lmin, lmax), (right, rmin, rmax)):
+        internal = child >= 0
+        c = child[internal]
+        umin = np.minimum(lmin[c], rmin[c])
+        umax = np.maximum(lmax[c], rmax[c])
+        np.testing.assert_array_equal(cmin[internal], umin)
+        np.testing.assert_array_equal(cmax[internal], umax)
+        assert (parent[c] == np.nonzero(internal)[0]).all()
+    # each leaf slot referenced exactly once
+    leaves = np.concatenate([~left[left < 0], ~right[right < 0]])
+    assert sorted(leaves.tolist()) == list(range(n))
+    g.close()
+
+
+def test_spheres(rt, oracle_cls):
+    sc = scenes.sphere_field()
+    orc = oracle_cls(sc)
+    d = orc.camera_rays(sc.fov, 160, 120)
+    dn = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([np.zeros_like(dn), dn], 1)
+    rng = np.random.RandomState(1)
+    pts = np.array([m.position for m in sc.meshes], np.float32)
+    dirs = (pts[rng.randint(0, len(pts), 4000)] + rng.normal(0, 1.5, (4000, 3))).astype(np.float32)
+    rays2 = np.concatenate([rng.uniform(-1, 1, (4000, 3)).astype(np.float32), dirs], 1)
+    g = rt.RtHip(sc, geometry=rt.SPHERES)
+    for r in (rays, rays2):
+        a = orc.spheres_intersect(r)
+        b = g.intersect(r)
+        assert a["hit"].sum() > 50
+        np.testing.assert_array_equal(a["hit"], b["hit"])
+        hit = a["hit"] > 0
+        np.testing.assert_array_equal(a["index"][hit], b["material"][hit])
+        for f in ("position", "normal"):
+            assert_bits_equal(a["records"][f], b["records"][f], f)
+    cols = g.sphere_colors(len(sc.meshes))
+    a = orc.spheres_intersect(rays2)
+    hit = a["hit"] > 0
+    assert_bits_equal(cols[a["index"][hit]], a["diffuse"][hit], "srand(420) colours")
+    ro = np.concatenate([rng.uniform(-20, 20, (4000, 3)), rng.normal(0, 1, (4000, 3))], 1).astype(np.float32)
+    np.testing.assert_array_equal(orc.spheres_occlude(ro), g.occlude(ro))
+    g.close()
