@@ -105,7 +105,11 @@ typedef struct rt_hip_config {
 	float photon_absorb;      /* 0.6    rt_photon_map.cpp:45 */
 	uint64_t seed;            /* counter-RNG seed of the photon pass */
 	int profile;              /* 1: bracket the trace kernels with hipEvents (rt_hip_get_stats) */
-	int reserved;
+	float shadow_t_max;       /* 0: literal reference shadow test -- ANY hit along the un-normalised
+	                             light ray shadows, also beyond the light (rt_raytracer.cpp:113-117, whose
+	                             distance test compares ray->position with itself).  > 0: a hit shadows
+	                             only if t < shadow_t_max in units of |L| (1.0 = "before the light",
+	                             the evident intent); runs that use it must say so */
 } rt_hip_config;
 
 /* Kernel-time accounting for bench.py (only filled when config.profile != 0). */

@@ -50,7 +50,8 @@ def _p(a, t=c_float_p):
 
 class ShadeConfig(C.Structure):
     _fields_ = [("bounces", C.c_int), ("do_shadows", C.c_int), ("use_photon_map", C.c_int),
-                ("photon_estimate", C.c_int), ("photon_radius", C.c_float), ("geometry", C.c_int)]
+                ("photon_estimate", C.c_int), ("photon_radius", C.c_float), ("geometry", C.c_int),
+                ("shadow_t_max", C.c_float)]
 
 
 class Oracle:
@@ -240,11 +241,11 @@ class Oracle:
 
     # ---- shading --------------------------------------------------------------------------
     def render_texels(self, pos, nrm, material_id, bounces=2, do_shadows=0, use_photon_map=0, photon_estimate=100,
-                      photon_radius=1.0, geometry=0):
+                      photon_radius=1.0, geometry=0, shadow_t_max=0.0):
         pos, nrm = _f(pos), _f(nrm)
         mid = np.ascontiguousarray(material_id, dtype=np.int32)
         n = pos.shape[0]
-        cfg = ShadeConfig(bounces, do_shadows, use_photon_map, photon_estimate, photon_radius, geometry)
+        cfg = ShadeConfig(bounces, do_shadows, use_photon_map, photon_estimate, photon_radius, geometry, shadow_t_max)
         rgba = np.zeros((n, 4), np.uint8)
         rgbf = np.zeros((n, 3), np.float32)
         rays = C.c_int64(0)

@@ -620,9 +620,17 @@ void shade(ShadeCtx& c, const orc_ray* ray, Material material, bool has_hm, HitM
 				memset(&lr, 0, sizeof(lr));
 				st3(lr.origin, add(V, mul(N, bias)));
 				st3(lr.direction, L);
-				HitMat hm;
 				++c.rays;
-				if (accel_intersect(s, c.cfg->geometry, &lr, &hm)) {
+				bool blocked;
+				if (c.cfg->geometry == 0) {
+					float t = 0;
+					blocked = array_intersect(s, &lr, NULL, &t) >= 0;
+					// corrected variant (not the reference): only hits before shadow_t_max * |L|
+					if (blocked && c.cfg->shadow_t_max > 0.0f) blocked = t < c.cfg->shadow_t_max;
+				} else {
+					blocked = spheres_intersect(s, &lr) >= 0;
+				}
+				if (blocked) {
 					// distance = |ray->position - V| = 0 (rt_raytracer.cpp:115): any hit shadows
 					if (0.0f < norm(L)) shadow = (float)std::max(shadow - 0.4, 0.0);
 				}
@@ -1003,8 +1011,12 @@ void orc_render_texels(orc_scene* s, const orc_shade_config* cfg, int n, const f
 		st3(r.normal, ld3(nrm + 3 * i));
 		st3(r.direction, normalized(P));  // eye at the origin (prepass_vs.cpp:12-13)
 		V3 col = mk(0, 0, 0);
+		// ids past the user table address the per-sphere materials (sphere geometry only)
 		HitMat hm = {material_id[i], -1};
-		shade(c, &r, s->materials[material_id[i]], false, hm, &col, 0);
+		Material m0;
+		if (material_id[i] < (int)s->materials.size()) m0 = s->materials[material_id[i]];
+		else { hm.tri_material = -1; hm.sphere = material_id[i] - (int)s->materials.size(); m0 = material_of(s, hm); }
+		shade(c, &r, m0, false, hm, &col, 0);
 		if (rgb_float) st3(rgb_float + 3 * i, col);
 		// rt_raytracer.cpp:175-178
 		rgba[4 * i + 0] = (unsigned char)(std::min((int)col.x, 255));

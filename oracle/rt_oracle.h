@@ -28,6 +28,7 @@ typedef struct {
 	int photon_estimate;   /* 100 */
 	float photon_radius;   /* 1.0 */
 	int geometry;          /* 0 = triangles with AccelArray semantics, 1 = spheres */
+	float shadow_t_max;    /* 0 = literal (any hit shadows); > 0: only hits with t < shadow_t_max (triangles) */
 } orc_shade_config;
 
 orc_scene* orc_scene_create(void);

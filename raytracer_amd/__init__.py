@@ -40,7 +40,7 @@ class Config(C.Structure):
                 ("eps_det", C.c_float), ("eps_t", C.c_float), ("t_max", C.c_float), ("bounces", C.c_int),
                 ("do_shadows", C.c_int), ("use_photon_map", C.c_int), ("photon_count", C.c_int),
                 ("photon_estimate", C.c_int), ("photon_radius", C.c_float), ("photon_max_dist", C.c_float),
-                ("photon_absorb", C.c_float), ("seed", C.c_uint64), ("profile", C.c_int), ("reserved", C.c_int)]
+                ("photon_absorb", C.c_float), ("seed", C.c_uint64), ("profile", C.c_int), ("shadow_t_max", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -83,6 +83,16 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("librt_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                            "raytracer_amd has no CPU fallback")
+    # One HIP runtime per process: PyTorch's wheel bundles its own libamdhip64.  If librt_hip.so
+    # were loaded first it would bind /opt/rocm's copy and torch.cuda would then find no device
+    # (measured on the GPU box).  Importing torch first makes both share torch's runtime; callers
+    # that never use torch tensors are unaffected.
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     P = C.c_void_p
     L.rt_hip_last_error.restype = C.c_char_p

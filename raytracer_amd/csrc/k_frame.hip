@@ -290,10 +290,11 @@ __device__ __forceinline__ bool tile_is_mine(int pixel, int w, int tile, int ran
 __global__ __launch_bounds__(BLOCK) void k_init_nodes(const float* __restrict__ pos_rgb,
                                                       const float* __restrict__ nrm_rgba, int w, int h, int tile,
                                                       int rank, int nranks, int num_materials,
-                                                      NodeGeo* __restrict__ geo)
+                                                      NodeGeo* __restrict__ geo, int* __restrict__ active_count)
 {
 	int i = blockIdx.x * BLOCK + threadIdx.x;
-	if (i >= w * h) return;
+	bool active = false;
+	if (i < w * h) {
 	NodeGeo g;
 	float a = nrm_rgba[4 * (size_t)i + 3];
 	int mat = (a > 0.0f) ? ((int)a - 1) : -1;
@@ -309,13 +310,18 @@ __global__ __launch_bounds__(BLOCK) void k_init_nodes(const float* __restrict__ 
 	st3(g.I, mat >= 0 ? normalized3(P) : mk3(0, 0, 0));
 	g.parent = i; g.material = mat; g.branch = 0;
 	geo[i] = g;
+	active = mat >= 0;
+	}
+	uint64_t m = __ballot(active);
+	if (m && lane_id() == (int)__builtin_ctzll(m)) atomicAdd(active_count, (int)__popcll(m));
 }
 
 // Shadow rays: one lane per (light, node); lanes of a wave share the light, so the rays of a
 // wave converge on one point.  occl[node] gets bit `light` when the ray is blocked.
 __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const NodeGeo* __restrict__ geo, int n,
-                                                        unsigned int* __restrict__ occl)
+                                                        float shadow_t_max, unsigned int* __restrict__ occl)
 {
+	if (shadow_t_max > 0.0f) sv.tp.t_max = shadow_t_max;
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	int64_t idx = (int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
 	if (idx >= (int64_t)n * sv.num_lights) return;
@@ -749,9 +755,14 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 	RT_CHECK(ctx->d_occ.reserve((size_t)npix * 4 * 2));
 
 	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+	RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 64, st));
 	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(npix, BLOCK)), dim3(BLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, tile, rank,
-	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>());
+	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), qcount + 8);
 	RT_HIP_CHECK(hipGetLastError());
+	int active0 = 0;
+	RT_HIP_CHECK(hipMemcpyAsync(&active0, qcount + 8, 4, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	const bool shadow_rays = !ctx->cfg.use_photon_map && ctx->cfg.do_shadows && sv.num_lights > 0;
 
 	int64_t rays = 0;
 	int levels = 0;
@@ -784,10 +795,13 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 			int64_t total = (int64_t)n * sv.num_lights;
 			size_t lds = sv.use_bvh ? (size_t)sv.stack_depth * TRACE_BLOCK * sizeof(int) : 0;
 			RT_CHECK(rt_begin_trace_timing(ctx));
-			hipLaunchKernelGGL(k_shadow, dim3(nblocks(total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n, occl);
+			hipLaunchKernelGGL(k_shadow, dim3(nblocks(total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
+			                   ctx->cfg.shadow_t_max, occl);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_CHECK(rt_end_trace_timing(ctx));
-			// rays are only issued for active nodes; counted exactly below from the node census
+			int64_t issued = (int64_t)(L == 0 ? active0 : n) * sv.num_lights;  // only active nodes trace
+			rays += issued;
+			ctx->stats.rays_any += issued;
 		}
 
 		// queue buffers sized for one ray per node
@@ -861,7 +875,8 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 	RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
 	ctx->stats.frame_ms += ms;
 	ctx->stats.frames += 1;
-	ctx->last_frame_rays = rays;  // shadow rays are added by the caller-visible census in rt_api.hip
+	(void)shadow_rays;
+	ctx->last_frame_rays = rays;
 	// stash per-level counts for the census
 	ctx->last_count = levels;
 	RT_CHECK(rt_collect_timing(ctx));

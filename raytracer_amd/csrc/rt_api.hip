@@ -175,6 +175,7 @@ int rt_hip_default_config(rt_hip_config* cfg)
 	cfg->photon_absorb = 0.6f;
 	cfg->seed = 42;
 	cfg->profile = 0;
+	cfg->shadow_t_max = 0.0f;
 	return RT_HIP_OK;
 }
 
@@ -252,6 +253,7 @@ int rt_hip_set_config(rt_hip_ctx* ctx, const rt_hip_config* cfg)
 	ctx->cfg.photon_absorb = cfg->photon_absorb;
 	ctx->cfg.seed = cfg->seed;
 	ctx->cfg.profile = cfg->profile;
+	ctx->cfg.shadow_t_max = cfg->shadow_t_max;
 	ctx->cfg.eps_det = cfg->eps_det;
 	ctx->cfg.eps_t = cfg->eps_t;
 	ctx->cfg.t_max = cfg->t_max;
