@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- secondary-ray throughput of the HIP hot path on the BASELINE.json workload.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1 is launched by torch.distributed.run)
+
+Workload (config.workload): "atrium-262k-1080p" = BASELINE.json configs[2], the configuration the
+metric ("secondary Mrays/s + ms/frame @1080p, 1/2/4/8 MI355X") is quoted on: a ~262k-triangle
+procedural atrium (real Sponza cannot be fetched offline), GPU LBVH, 1080p G-buffer resident in
+HBM, Gen-1 shading with shadow + reflection + refraction rays, 2 bounces.
+
+A step = one frame's worth of texels per GPU.  At N GPUs the job renders N frames (N fields of
+view) per step and every frame is split over the ranks by interleaved 64x64 tiles, so each rank
+traces one frame's worth of texels (weak scaling: per-GPU work is fixed).  The scene and the LBVH
+are replicated; the only collective is the gather of the finished tiles (RCCL all_reduce of the
+disjoint RGBA8 tile images), inside the timed region.
+
+value = secondary rays issued by all ranks / wall time (barrier + synchronize on both sides, max
+over ranks).  roofline = the dominant kernel (the shadow any-hit traversal k_shadow) against HBM:
+algorithmic bytes = rays x (64 B x nodes/ray + 48 B x tris/ray + 48 B ray in/out), with nodes/ray
+and tris/ray counted on the device by a census pass over the identical frame.  cpu_baseline = the
+compiled reference's own RayTracer::processRays (oracle/_ref, kind "reference") or the oracle's
+restatement (kind "port") on a bounded sample of the same G-buffer, single thread as the
+reference is.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="atrium-262k-1080p",
+                    choices=["atrium-262k-1080p", "atrium-1m-1080p", "atrium-1m-4k", "cornell-1080p", "atrium-8k-small"])
+    ap.add_argument("--shadow-mode", default="corrected", choices=["corrected", "literal"],
+                    help="corrected: a hit shadows only before the light (shadow_t_max=1); literal: the reference's any-hit")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="G-buffer texels fed to the CPU baseline (0 = auto)")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    "atrium-262k-1080p": dict(tris=262144, w=1920, h=1080),
+    "atrium-1m-1080p": dict(tris=1048576, w=1920, h=1080),
+    "atrium-1m-4k": dict(tris=1048576, w=3840, h=2160),
+    "cornell-1080p": dict(tris=0, w=1920, h=1080),
+    "atrium-8k-small": dict(tris=8192, w=480, h=270),
+}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd import scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    W, H = wl["w"], wl["h"]
+    scene = scenes.cornell() if wl["tris"] == 0 else scenes.atrium(wl["tris"])
+    shadow_t_max = 1.0 if args.shadow_mode == "corrected" else 0.0
+    g = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_LBVH, device=local_rank, profile=1, bounces=2, do_shadows=1,
+                 shadow_t_max=shadow_t_max)
+    build_stats = g.stats()
+
+    # ---- inputs resident in HBM: one G-buffer per frame of the step -------------------------
+    nframes = world
+    npix = W * H
+    gb_n, gb_p = [], []
+    for f in range(nframes):
+        d_n = torch.zeros(npix * 4, dtype=torch.float32, device=dev)
+        d_p = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+        g.render_gbuffer_device(scene.fov - 0.03 * f, W, H, d_n, d_p)
+        gb_n.append(d_n)
+        gb_p.append(d_p)
+    g.sync()
+    tiles = torch.zeros(nframes, npix * 4, dtype=torch.uint8, device=dev)   # this rank's tiles (others stay 0)
+    frames = torch.zeros_like(tiles)                                        # gathered frames
+
+    def step():
+        rays = 0
+        for f in range(nframes):
+            g.render_tiles_device(gb_p[f], gb_n[f], W, H, 64, rank, world, tiles[f])
+            rays += g.last_frame_rays()
+        if world > 1:
+            frames.copy_(tiles)
+            dist.all_reduce(frames, op=dist.ReduceOp.SUM)   # tiles are disjoint: SUM assembles the frames
+        return rays
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    g.reset_stats()
+    t0 = time.perf_counter()
+    rays_rank = 0
+    for _ in range(args.steps):
+        rays_rank += step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = g.stats()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ry = torch.tensor([float(rays_rank)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ry, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_rays = float(ry.item())
+
+    # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------
+    any_ms, any_launches, rays_any = st["any_ms"], st["any_launches"], st["rays_any"]
+    clo_ms, clo_launches, rays_clo = st["closest_ms"], st["closest_launches"], st["rays_closest"]
+    # census pass: same frame(s), counting node visits / triangle tests per ray (untimed)
+    g.set_config(census=1, profile=0)
+    g.reset_stats()
+    for f in range(nframes):
+        g.render_tiles_device(gb_p[f], gb_n[f], W, H, 64, rank, world, tiles[f])
+    cs = g.stats()
+    g.set_config(census=0, profile=1)
+    nodes_any = cs["census_nodes_any"] / max(cs["census_rays_any"], 1)
+    tris_any = cs["census_tris_any"] / max(cs["census_rays_any"], 1)
+    nodes_clo = cs["census_nodes_closest"] / max(cs["census_rays_closest"], 1)
+    tris_clo = cs["census_tris_closest"] / max(cs["census_rays_closest"], 1)
+    bytes_per_any = 64.0 * nodes_any + 48.0 * tris_any + 48.0
+    bytes_per_clo = 64.0 * nodes_clo + 48.0 * tris_clo + 48.0
+    dominant = "k_shadow(any-hit)" if any_ms >= clo_ms else "k_bvh(closest)"
+    if any_ms >= clo_ms:
+        rays_per_launch = rays_any / max(any_launches, 1)
+        avg_ms = any_ms / max(any_launches, 1)
+        bpr = bytes_per_any
+    else:
+        rays_per_launch = rays_clo / max(clo_launches, 1)
+        avg_ms = clo_ms / max(clo_launches, 1)
+        bpr = bytes_per_clo
+    achieved = (rays_per_launch * bpr) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": dominant, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": round(rays_per_launch, 1),
+                "nodes_per_ray": round(nodes_any if any_ms >= clo_ms else nodes_clo, 2),
+                "tris_per_ray": round(tris_any if any_ms >= clo_ms else tris_clo, 2),
+                "bytes_per_ray": round(bpr, 1),
+                "kernel_mrays_per_s": round(rays_per_launch / (avg_ms * 1e-3) / 1e6, 1) if avg_ms > 0 else 0.0,
+                "closest": {"avg_launch_ms": round(clo_ms / max(clo_launches, 1), 4),
+                            "rays_per_launch": round(rays_clo / max(clo_launches, 1), 1),
+                            "nodes_per_ray": round(nodes_clo, 2), "tris_per_ray": round(tris_clo, 2)}}
+
+    # ---- CPU baseline on rank 0 (N = 1 only) ------------------------------------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(scene, gb_n[0], gb_p[0], W, H, args.cpu_sample)
+
+    if rank == 0:
+        out = {
+            "metric": "secondary Mrays/s", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene": scene.name, "triangles": scene.num_tris, "width": W, "height": H,
+                       "frames_per_step": nframes, "tile": 64, "bounces": 2, "lights": len(scene.lights),
+                       "shadows": args.shadow_mode, "accel": "lbvh", "parallelism": "tiles x%d" % world,
+                       "rays_per_frame": round(total_rays / args.steps / nframes, 1),
+                       "ms_per_frame": round(elapsed / args.steps * 1e3, 3),
+                       "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"]},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(scene, d_n, d_p, W, H, sample):
+    """RayTracer::processRays of the compiled reference (or the oracle port) on a bounded sample."""
+    from oracle import pyoracle
+    nr = d_n.cpu().numpy().reshape(-1, 4)
+    po = d_p.cpu().numpy().reshape(-1, 3)
+    sel = np.nonzero(nr[:, 3] > 0)[0]
+    kind = "reference" if pyoracle.have_ref() else "port"
+    cpu = pyoracle.Ref(scene) if kind == "reference" else pyoracle.Oracle(scene)
+    nrm = (nr[:, :3].astype(np.float64) * 2.0 - 1.0).astype(np.float32)
+    # calibrate on 1/64 of the texels, then size the sample for about 15 s
+    probe = sel[::64]
+    t0 = time.perf_counter()
+    cpu.process_rays(po[probe], nrm[probe])
+    dt = time.perf_counter() - t0
+    if sample <= 0:
+        rate = len(probe) / max(dt, 1e-6)
+        sample = int(min(len(sel), max(len(probe), rate * 15.0)))
+    stride = max(len(sel) // sample, 1)
+    pick = sel[::stride]
+    t0 = time.perf_counter()
+    r = cpu.process_rays(po[pick], nrm[pick])
+    dt = time.perf_counter() - t0
+    return {"value": round(len(pick) / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": kind,
+            "sample": "RayTracer::processRays (DACRT, reflection rays, closest hit) on %d of the %d covered 1080p "
+                      "G-buffer texels (every %dth), %.1f s, %d hits" % (len(pick), len(sel), stride, dt, len(r["records"]))}
+
+
+if __name__ == "__main__":
+    main()

@@ -110,14 +110,20 @@ typedef struct rt_hip_config {
 	                             distance test compares ray->position with itself).  > 0: a hit shadows
 	                             only if t < shadow_t_max in units of |L| (1.0 = "before the light",
 	                             the evident intent); runs that use it must say so */
+	int census;               /* 1: trace kernels also count BVH node visits / triangle tests (slower) */
+	int reserved;
 } rt_hip_config;
 
-/* Kernel-time accounting for bench.py (only filled when config.profile != 0). */
+/* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent
+ * pairs around every trace launch on the context's stream); the census sums only when
+ * config.census != 0 (the trace kernels then also count node visits and triangle tests). */
 typedef struct rt_hip_stats {
-	double trace_ms;          /* summed device time of the BVH / brute-force trace kernels */
-	int64_t trace_launches;
+	double closest_ms;        /* summed device time of closest-hit trace launches */
+	int64_t closest_launches;
 	int64_t rays_closest;     /* closest-hit rays issued */
-	int64_t rays_any;         /* any-hit (shadow) rays issued */
+	double any_ms;            /* summed device time of any-hit (shadow) trace launches */
+	int64_t any_launches;
+	int64_t rays_any;         /* any-hit rays issued */
 	double build_ms;          /* last rt_hip_update: soup + LBVH build */
 	int64_t num_tris;
 	int64_t num_nodes;
@@ -125,6 +131,8 @@ typedef struct rt_hip_stats {
 	int32_t reserved;
 	double frame_ms;          /* summed device time of whole frames (render / process entries) */
 	int64_t frames;
+	uint64_t census_nodes_closest, census_tris_closest, census_rays_closest;
+	uint64_t census_nodes_any, census_tris_any, census_rays_any;
 } rt_hip_stats;
 
 /* ---- life cycle --------------------------------------------------------------------------- */

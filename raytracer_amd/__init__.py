@@ -40,13 +40,17 @@ class Config(C.Structure):
                 ("eps_det", C.c_float), ("eps_t", C.c_float), ("t_max", C.c_float), ("bounces", C.c_int),
                 ("do_shadows", C.c_int), ("use_photon_map", C.c_int), ("photon_count", C.c_int),
                 ("photon_estimate", C.c_int), ("photon_radius", C.c_float), ("photon_max_dist", C.c_float),
-                ("photon_absorb", C.c_float), ("seed", C.c_uint64), ("profile", C.c_int), ("shadow_t_max", C.c_float)]
+                ("photon_absorb", C.c_float), ("seed", C.c_uint64), ("profile", C.c_int), ("shadow_t_max", C.c_float), ("census", C.c_int), ("reserved", C.c_int)]
 
 
 class Stats(C.Structure):
-    _fields_ = [("trace_ms", C.c_double), ("trace_launches", C.c_int64), ("rays_closest", C.c_int64),
-                ("rays_any", C.c_int64), ("build_ms", C.c_double), ("num_tris", C.c_int64), ("num_nodes", C.c_int64),
-                ("bvh_depth", C.c_int32), ("reserved", C.c_int32), ("frame_ms", C.c_double), ("frames", C.c_int64)]
+    _fields_ = [("closest_ms", C.c_double), ("closest_launches", C.c_int64), ("rays_closest", C.c_int64),
+                ("any_ms", C.c_double), ("any_launches", C.c_int64), ("rays_any", C.c_int64),
+                ("build_ms", C.c_double), ("num_tris", C.c_int64), ("num_nodes", C.c_int64),
+                ("bvh_depth", C.c_int32), ("reserved", C.c_int32), ("frame_ms", C.c_double), ("frames", C.c_int64),
+                ("census_nodes_closest", C.c_uint64), ("census_tris_closest", C.c_uint64),
+                ("census_rays_closest", C.c_uint64), ("census_nodes_any", C.c_uint64),
+                ("census_tris_any", C.c_uint64), ("census_rays_any", C.c_uint64)]
 
 
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)

@@ -318,31 +318,42 @@ __global__ __launch_bounds__(BLOCK) void k_init_nodes(const float* __restrict__ 
 
 // Shadow rays: one lane per (light, node); lanes of a wave share the light, so the rays of a
 // wave converge on one point.  occl[node] gets bit `light` when the ray is blocked.
+template <bool CENSUS>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const NodeGeo* __restrict__ geo, int n,
-                                                        float shadow_t_max, unsigned int* __restrict__ occl)
+                                                        float shadow_t_max, unsigned int* __restrict__ occl,
+                                                        unsigned long long* census)
 {
 	if (shadow_t_max > 0.0f) sv.tp.t_max = shadow_t_max;
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	int64_t idx = (int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
-	if (idx >= (int64_t)n * sv.num_lights) return;
-	int light = (int)(idx / n), i = (int)(idx % n);
-	const NodeGeo g = geo[i];
-	if (g.material < 0) return;
-	f3 V = ld3(g.V), N = ld3(g.N);
-	f3 L = ld3(sv.lights[light].position) - V;
-	f3 O = V + N * 0.1f;  // bias = 0.1 (rt_raytracer.cpp:79,112)
-	bool blocked;
-	if (sv.num_spheres > 0 && sv.num_tris == 0) {
-		blocked = false;
-		f3 X, Nn;
-		for (int k = 0; k < sv.num_spheres; ++k)
-			if (sphere_test_ref(sv.spheres[k], L, L, X, Nn)) { blocked = true; break; }
-	} else {
-		Hit best;
-		blocked = scene_trace<true>(sv, O, L, best, smem + threadIdx.x, TRACE_BLOCK);
+	uint32_t cn = 0, ct = 0;
+	bool active = false;
+	if (idx < (int64_t)n * sv.num_lights) {
+		int light = (int)(idx / n), i = (int)(idx % n);
+		const NodeGeo g = geo[i];
+		if (g.material >= 0) {
+			active = true;
+			f3 V = ld3(g.V), N = ld3(g.N);
+			f3 L = ld3(sv.lights[light].position) - V;
+			f3 O = V + N * 0.1f;  // bias = 0.1 (rt_raytracer.cpp:79,112)
+			bool blocked;
+			if (sv.num_spheres > 0 && sv.num_tris == 0) {
+				blocked = false;
+				f3 X, Nn;
+				for (int k = 0; k < sv.num_spheres; ++k)
+					if (sphere_test_ref(sv.spheres[k], L, L, X, Nn)) { blocked = true; break; }
+			} else if (sv.use_bvh) {
+				Hit best;
+				blocked = bvh_trace<true, CENSUS>(sv, O, L, best, smem + threadIdx.x, TRACE_BLOCK, cn, ct);
+			} else {
+				Hit best;
+				blocked = brute_trace<true>(sv, O, L, best);
+			}
+			// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116)
+			if (blocked && 0.0f < norm3(L)) atomicOr(&occl[i], 1u << light);
+		}
 	}
-	// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116)
-	if (blocked && 0.0f < norm3(L)) atomicOr(&occl[i], 1u << light);
+	if (CENSUS && census) census_add(census, cn, ct, active);
 }
 
 // Per node: lambert / shadow -> F, and the reflection ray if this level may recurse.
@@ -795,10 +806,15 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 			int64_t total = (int64_t)n * sv.num_lights;
 			size_t lds = sv.use_bvh ? (size_t)sv.stack_depth * TRACE_BLOCK * sizeof(int) : 0;
 			RT_CHECK(rt_begin_trace_timing(ctx));
-			hipLaunchKernelGGL(k_shadow, dim3(nblocks(total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
-			                   ctx->cfg.shadow_t_max, occl);
+			unsigned long long* cen = rt_census_ptr(ctx, 1);
+			if (cen)
+				hipLaunchKernelGGL(k_shadow<true>, dim3(nblocks(total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
+				                   ctx->cfg.shadow_t_max, occl, cen);
+			else
+				hipLaunchKernelGGL(k_shadow<false>, dim3(nblocks(total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
+				                   ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
-			RT_CHECK(rt_end_trace_timing(ctx));
+			RT_CHECK(rt_end_trace_timing(ctx, 1));
 			int64_t issued = (int64_t)(L == 0 ? active0 : n) * sv.num_lights;  // only active nodes trace
 			rays += issued;
 			ctx->stats.rays_any += issued;

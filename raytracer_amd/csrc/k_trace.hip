@@ -53,18 +53,20 @@ template <bool ANY, bool CENSUS>
 __global__ __launch_bounds__(BVH_BLOCK) void k_bvh(SceneView sv, const float* __restrict__ org,
                                                    const float* __restrict__ dir, int n, Hit* __restrict__ hits,
                                                    uint8_t* __restrict__ occ, uint32_t* __restrict__ nv,
-                                                   uint32_t* __restrict__ nt)
+                                                   uint32_t* __restrict__ nt, unsigned long long* census)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	int i = blockIdx.x * BVH_BLOCK + threadIdx.x;
-	if (i >= n) return;
-	f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
-	Hit best;
 	uint32_t cn = 0, ct = 0;
-	bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, smem + threadIdx.x, BVH_BLOCK, cn, ct);
-	if (CENSUS) { nv[i] = cn; nt[i] = ct; }
-	if (ANY) { if (occ) occ[i] = any ? 1 : 0; }
-	else if (hits) hits[i] = best;
+	if (i < n) {
+		f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
+		Hit best;
+		bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, smem + threadIdx.x, BVH_BLOCK, cn, ct);
+		if (CENSUS && nv) { nv[i] = cn; nt[i] = ct; }
+		if (ANY) { if (occ) occ[i] = any ? 1 : 0; }
+		else if (hits) hits[i] = best;
+	}
+	if (CENSUS && census) census_add(census, cn, ct, i < n);
 }
 
 // ---- spheres ----------------------------------------------------------------------------------
@@ -112,16 +114,22 @@ int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, i
 	if (n <= 0) return RT_HIP_OK;
 	SceneView sv = rt_scene_view(ctx);
 	RT_CHECK(rt_begin_trace_timing(ctx));
-	if (sv.use_bvh) {
+	unsigned long long* cen = rt_census_ptr(ctx, 0);
+	if (sv.use_bvh && cen) {
+		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
+		hipLaunchKernelGGL((k_bvh<false, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		                   d_org, d_dir, n, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cen);
+	} else if (sv.use_bvh) {
 		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
 		hipLaunchKernelGGL((k_bvh<false, false>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+		                   d_org, d_dir, n, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+		                   (unsigned long long*)nullptr);
 	} else {
 		hipLaunchKernelGGL((k_brute<0>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv.tris, sv.num_tris,
 		                   d_org, d_dir, n, sv.tp, d_hits, (uint8_t*)nullptr);
 	}
 	RT_HIP_CHECK(hipGetLastError());
-	RT_CHECK(rt_end_trace_timing(ctx));
+	RT_CHECK(rt_end_trace_timing(ctx, 0));
 	ctx->stats.rays_closest += n;
 	return RT_HIP_OK;
 }
@@ -131,16 +139,22 @@ int rt_launch_any(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n
 	if (n <= 0) return RT_HIP_OK;
 	SceneView sv = rt_scene_view(ctx);
 	RT_CHECK(rt_begin_trace_timing(ctx));
-	if (sv.use_bvh) {
+	unsigned long long* cen = rt_census_ptr(ctx, 1);
+	if (sv.use_bvh && cen) {
+		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
+		hipLaunchKernelGGL((k_bvh<true, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		                   d_org, d_dir, n, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr, cen);
+	} else if (sv.use_bvh) {
 		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
 		hipLaunchKernelGGL((k_bvh<true, false>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr);
+		                   d_org, d_dir, n, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr,
+		                   (unsigned long long*)nullptr);
 	} else {
 		hipLaunchKernelGGL((k_brute<1>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv.tris, sv.num_tris,
 		                   d_org, d_dir, n, sv.tp, (Hit*)nullptr, d_occ);
 	}
 	RT_HIP_CHECK(hipGetLastError());
-	RT_CHECK(rt_end_trace_timing(ctx));
+	RT_CHECK(rt_end_trace_timing(ctx, 1));
 	ctx->stats.rays_any += n;
 	return RT_HIP_OK;
 }
@@ -170,10 +184,10 @@ int rt_launch_census(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, in
 	size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
 	if (any_hit)
 		hipLaunchKernelGGL((k_bvh<true, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt);
+		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt, (unsigned long long*)nullptr);
 	else
 		hipLaunchKernelGGL((k_bvh<false, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt);
+		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt, (unsigned long long*)nullptr);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }

@@ -100,31 +100,49 @@ int rt_begin_trace_timing(rt_hip_ctx* ctx)
 		RT_HIP_CHECK(hipEventCreate(&a));
 		RT_HIP_CHECK(hipEventCreate(&b));
 		ctx->trace_events.push_back(std::make_pair(a, b));
+		ctx->trace_event_class.push_back(0);
 	}
 	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].first, ctx->stream));
 	return RT_HIP_OK;
 }
 
-int rt_end_trace_timing(rt_hip_ctx* ctx)
+int rt_end_trace_timing(rt_hip_ctx* ctx, int cls)
 {
+	if (cls) ctx->stats.any_launches += 1; else ctx->stats.closest_launches += 1;
 	if (!ctx->cfg.profile) return RT_HIP_OK;
 	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].second, ctx->stream));
+	ctx->trace_event_class[ctx->trace_events_used] = cls;
 	++ctx->trace_events_used;
-	ctx->stats.trace_launches += 1;
 	return RT_HIP_OK;
+}
+
+unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls)
+{
+	if (!ctx->cfg.census) return nullptr;
+	if (!ctx->d_census.p) {
+		if (ctx->d_census.reserve(64) != RT_HIP_OK) return nullptr;
+		if (hipMemsetAsync(ctx->d_census.p, 0, 64, ctx->stream) != hipSuccess) return nullptr;
+	}
+	return ctx->d_census.as<unsigned long long>() + (cls ? 3 : 0);
 }
 
 // Fold the pending event pairs into stats (requires the stream to be idle or syncs on the events).
 int rt_collect_timing(rt_hip_ctx* ctx)
 {
-	if (!ctx->cfg.profile) return RT_HIP_OK;
+	if (!ctx->cfg.profile) ctx->trace_events_used = 0;
 	for (size_t i = 0; i < ctx->trace_events_used; ++i) {
 		RT_HIP_CHECK(hipEventSynchronize(ctx->trace_events[i].second));
 		float ms = 0;
 		RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->trace_events[i].first, ctx->trace_events[i].second));
-		ctx->stats.trace_ms += ms;
+		if (ctx->trace_event_class[i]) ctx->stats.any_ms += ms; else ctx->stats.closest_ms += ms;
 	}
 	ctx->trace_events_used = 0;
+	if (ctx->cfg.census && ctx->d_census.p) {
+		unsigned long long c[6];
+		RT_HIP_CHECK(hipMemcpy(c, ctx->d_census.p, sizeof(c), hipMemcpyDeviceToHost));
+		ctx->stats.census_nodes_closest = c[0]; ctx->stats.census_tris_closest = c[1]; ctx->stats.census_rays_closest = c[2];
+		ctx->stats.census_nodes_any = c[3]; ctx->stats.census_tris_any = c[4]; ctx->stats.census_rays_any = c[5];
+	}
 	return RT_HIP_OK;
 }
 
@@ -136,6 +154,7 @@ static float float_threshold_of_double(double d)
 	return f;
 }
 
+// census sums are fetched even when profiling is off
 static int check_ctx(rt_hip_ctx* ctx)
 {
 	if (!ctx) { rt_set_error("null context"); return RT_HIP_ERR_ARG; }
@@ -226,7 +245,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_hits, &ctx->d_occ, &ctx->d_in_a, &ctx->d_in_b, &ctx->d_records, &ctx->d_offsets, &ctx->d_keys,
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
-	                  &ctx->d_cell_start, &ctx->d_photon_tmp};
+	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);
@@ -254,6 +273,7 @@ int rt_hip_set_config(rt_hip_ctx* ctx, const rt_hip_config* cfg)
 	ctx->cfg.seed = cfg->seed;
 	ctx->cfg.profile = cfg->profile;
 	ctx->cfg.shadow_t_max = cfg->shadow_t_max;
+	ctx->cfg.census = cfg->census;
 	ctx->cfg.eps_det = cfg->eps_det;
 	ctx->cfg.eps_t = cfg->eps_t;
 	ctx->cfg.t_max = cfg->t_max;
@@ -671,6 +691,7 @@ int rt_hip_reset_stats(rt_hip_ctx* ctx)
 	RT_CHECK(rt_collect_timing(ctx));
 	double build = ctx->stats.build_ms;
 	memset(&ctx->stats, 0, sizeof(ctx->stats));
+	if (ctx->d_census.p) RT_HIP_CHECK(hipMemset(ctx->d_census.p, 0, 64));
 	ctx->stats.build_ms = build;
 	ctx->stats.num_tris = ctx->num_tris;
 	ctx->stats.num_nodes = ctx->num_nodes;

@@ -76,7 +76,9 @@ struct rt_hip_ctx {
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;  // pending (profile mode)
+	std::vector<int> trace_event_class;                           // 0 closest, 1 any
 	size_t trace_events_used = 0;
+	DevBuf d_census;                                              // 6 x u64 (census mode)
 
 	std::vector<HostMesh> meshes;
 	std::vector<HostSphere> spheres;
@@ -114,7 +116,8 @@ struct rt_hip_ctx {
 
 SceneView rt_scene_view(const rt_hip_ctx* ctx);
 int rt_begin_trace_timing(rt_hip_ctx* ctx);
-int rt_end_trace_timing(rt_hip_ctx* ctx);
+int rt_end_trace_timing(rt_hip_ctx* ctx, int cls);
+unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls);  // nullptr unless cfg.census
 int rt_collect_timing(rt_hip_ctx* ctx);
 int rt_ensure_pinned(void** p, size_t* cap, size_t bytes);
 

@@ -68,6 +68,22 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 	return found;
 }
 
+// Census mode: wave-reduce the per-ray counters, one 64-bit atomic triple per wave.
+__device__ __forceinline__ void census_add(unsigned long long* census, uint32_t nodes, uint32_t tris, bool active)
+{
+	uint32_t a = nodes, b = tris, c = active ? 1u : 0u;
+	for (int off = 32; off >= 1; off >>= 1) {
+		a += __shfl_xor(a, off);
+		b += __shfl_xor(b, off);
+		c += __shfl_xor(c, off);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		atomicAdd(&census[0], (unsigned long long)a);
+		atomicAdd(&census[1], (unsigned long long)b);
+		atomicAdd(&census[2], (unsigned long long)c);
+	}
+}
+
 // Brute-force loop over sv.tris with the same contract (used when the scene has no BVH).
 template <bool ANY>
 __device__ __forceinline__ bool brute_trace(const SceneView& sv, f3 O, f3 D, Hit& best)
