@@ -18,6 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "librt_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libref_oracle.so")
+DROPIN_SO = os.path.join(HERE, "_ref", "libref_dropin.so")  # reference objects + AccelHip shim (GPU only)
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
@@ -34,6 +35,8 @@ def build(ref: bool = True) -> None:
     subprocess.check_call(["make", "-s", "-C", HERE, "librt_oracle.so"])
     if ref and os.path.isdir("/root/reference/raytracer"):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        if os.path.exists(os.path.join(HERE, "..", "raytracer_amd", "librt_hip.so")):
+            subprocess.check_call(["make", "-s", "-C", HERE, "dropin"])
 
 
 def have_ref() -> bool:
@@ -288,10 +291,11 @@ class Oracle:
 class Ref:
     """The compiled reference behind oracle/ref_harness.cpp (process-global state)."""
 
-    def __init__(self, scene=None):
-        if not have_ref():
-            raise RuntimeError("compiled reference not built (oracle/_ref/libref_oracle.so)")
-        self.lib = C.CDLL(REF_SO)
+    def __init__(self, scene=None, so_path=None):
+        so_path = so_path or REF_SO
+        if not os.path.exists(so_path):
+            raise RuntimeError("compiled reference not built (%s)" % so_path)
+        self.lib = C.CDLL(so_path)
         L = self.lib
         L.ref_add_material.argtypes = [c_float_p, c_float_p, C.c_float, C.c_float, C.c_float, C.c_float]
         L.ref_add_mesh.argtypes = [c_float_p, c_float_p, c_float_p, C.c_int, c_u32_p, C.c_int, c_float_p, C.c_int, c_float_p]

@@ -379,3 +379,77 @@ void ref_camera_rays(float fov, int w, int h, float* out_dir)
 }
 
 }  // extern "C"
+
+// ---- drop-in demonstration (libref_dropin.so only) ----------------------------------------------
+// The reference's own object code (PhotonMap::generate, rt_photon_map.cpp:86) driving the HIP back
+// end through the IAccel interface: AccelHip (raytracer_amd/host/rt_accel_hip.cpp, compiled here
+// against the reference's headers) takes AccelArray's place.  Built by `make -C oracle dropin`.
+#ifdef WITH_ACCEL_HIP
+#include "rt_accel_hip.h"
+
+namespace {
+AccelHip* g_hip = nullptr;
+RayTracerHip* g_rthip = nullptr;
+}
+
+extern "C" {
+
+int dropin_photon_generate(int count, long long* seed_used)
+{
+	if (!g.scene) {
+		g.scene = (Scene*)calloc(1, sizeof(Scene));
+		for (size_t i = 0; i < g.lights.size(); ++i) g.scene->lights.push_back(g.lights[i]);
+	}
+	if (!g_hip) {
+		g_hip = new AccelHip(0, 0);
+		if (!g_hip->ok()) return -2;
+		for (size_t i = 0; i < g.meshes.size(); ++i) g_hip->addMesh(g.meshes[i]);
+		g_hip->update();
+	}
+	for (int attempt = 0; attempt < 20; ++attempt) {
+		PhotonMap* pm = new PhotonMap();
+		time_t t0 = time(NULL);
+		pm->generate(g.scene, g_hip, count);
+		time_t t1 = time(NULL);
+		if (t0 == t1) {
+			g.pmap = pm;
+			*seed_used = (long long)t0;
+			return (int)pm->photons.size();
+		}
+	}
+	return -1;
+}
+
+int dropin_process_rays(int count, const float* positions, const float* normals, void* out_records,
+                        int* out_offset_material, int* out_offset_end, int* n_materials)
+{
+	if (!g_rthip) {
+		g_rthip = new RayTracerHip(0);
+		for (size_t i = 0; i < g.meshes.size(); ++i) g_rthip->addMesh(g.meshes[i]);
+	}
+	std::vector<Eigen::Vector3f> pos(count), nrm(count);
+	memcpy(pos.data(), positions, sizeof(float) * 3 * count);
+	memcpy(nrm.data(), normals, sizeof(float) * 3 * count);
+	Ray* results = NULL;
+	ResultOffset* offsets = NULL;
+	int nres = 0, nmat = 0;
+	void* cam_mem = calloc(1, sizeof(Camera));
+	g_rthip->processRays(*(Camera*)cam_mem, count, pos.data(), nrm.data(), &results, &offsets, &nres, &nmat);
+	free(cam_mem);
+	if (nres > 0) memcpy(out_records, results, (size_t)nres * sizeof(Ray));
+	for (int i = 0; i < nmat; ++i) {
+		out_offset_material[i] = material_index(offsets[i].first);
+		out_offset_end[i] = offsets[i].second;
+	}
+	*n_materials = nmat;
+	return nres;
+}
+
+void dropin_reset(void)
+{
+	delete g_hip; g_hip = nullptr;
+	delete g_rthip; g_rthip = nullptr;
+}
+
+}  // extern "C"
+#endif

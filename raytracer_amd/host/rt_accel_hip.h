@@ -1,0 +1,69 @@
+// raytracer_amd/host/rt_accel_hip.h -- the reference-side plug-in: `AccelHip` is a new IAccel
+// (raytracer/rt_iaccel.h:4-11) next to AccelArray / AccelSpheres, and `RayTracerHip` offers
+// RayTracer's two hot-path methods (raytracer/rt_raytracer.h:55-58) with identical signatures.
+// Both are thin: every call forwards to the C ABI of include/rt_hip.h (librt_hip.so).
+#pragma once
+
+#ifdef RT_HIP_IN_REFERENCE_TREE
+#include "data/data.h"
+#include "raytracer/rt_iaccel.h"
+typedef Eigen::Vector3f RtVec3;
+#else
+#include "rt_ref_mirror.h"
+typedef Vec3f RtVec3;
+#endif
+
+#include <map>
+#include <vector>
+
+struct rt_hip_ctx;
+
+class AccelHip : public IAccel
+{
+public:
+	// semantics: 0 = AccelArray (object space, 1e-5 thresholds, t < 1e6), 1 = AccelSpheres
+	explicit AccelHip(int semantics = 0, int device = 0);
+	~AccelHip();
+	virtual void addMesh(class Mesh* mesh);
+	virtual void update();
+	virtual bool occlude(class Ray* ray);
+	virtual bool intersect(class Ray* ray, struct Material** material);
+	// batch forms of the two queries (what the GPU is for; the virtuals are batches of one)
+	void intersectBatch(Ray* rays, int n, unsigned char* hit, Material** materials);
+	void occludeBatch(const Ray* rays, int n, unsigned char* occluded);
+	const char* lastError() const;
+	bool ok() const { return ctx != 0; }
+
+private:
+	AccelHip(const AccelHip&);
+	AccelHip& operator=(const AccelHip&);
+	int materialId(Material* m);
+	void sync();
+	rt_hip_ctx* ctx;
+	int semantics;
+	bool dirty;
+	std::vector<Material*> materials;      // id -> Material* (borrowed, owned by Scene)
+	std::map<Material*, int> material_ids;
+	std::vector<Material*> sphere_materials;  // AccelSpheres hands out its own Material per sphere
+};
+
+class RayTracerHip
+{
+public:
+	explicit RayTracerHip(int device = 0);
+	~RayTracerHip();
+	void addMesh(struct Mesh* mesh);                                     // rt_raytracer.cpp:69
+	void processRays(const class Camera& camera, int count, RtVec3* positions, RtVec3* normals, Ray** results,
+	                 ResultOffset** result_offsets, int* out_result_count, int* out_material_count);  // :428
+	const char* lastError() const;
+
+private:
+	RayTracerHip(const RayTracerHip&);
+	RayTracerHip& operator=(const RayTracerHip&);
+	rt_hip_ctx* ctx;
+	bool dirty;
+	std::vector<Mesh*> meshes;
+	std::vector<Material*> materials;
+	std::map<Material*, int> material_ids;
+	std::vector<ResultOffset> offset_vec;   // Material* restored from the dense ids
+};
