@@ -1,18 +1,405 @@
-// raytracer_amd/csrc/k_photon.hip -- GPU photon pass (placeholder until the grid kernels land).
-#include "rt_ctx.h"
+// raytracer_amd/csrc/k_photon.hip -- the photon map on the GPU (raytracer/rt_photon_map.cpp).
+//
+//   emission  PhotonMap::generate + emit_photon (rt_photon_map.cpp:86-124, :32-69): one lane per
+//             photon INDEX of the global sequence lights x photons_per_light, the reference's
+//             sampling arithmetic draw for draw, but the draws come from a counter RNG keyed by
+//             (seed, photon index, draw number) instead of the serial libc stream (:94), so any
+//             shard of indices yields the same photons on any number of GPUs.  Stored photons are
+//             compacted stably, i.e. they leave in index order.
+//   grid      uniform grid over the photon bounds, cell >= radius; photons counting-sorted by cell
+//             with the wave64 radix sort of k_sort.hip (stable: index order inside a cell).
+//   gather    PhotonMap::radiance_estimate (:149-208): candidates l2 < r^2, max_dist2 over ALL
+//             candidates, the `count` nearest (k-th smallest l2 found by bisection on the float bit
+//             pattern), Gaussian weights, the `#else` normalisation 1/(2 pi max_dist2) that the
+//             FILTER_GUASS typo selects, NaN for an empty neighbourhood.
+#include <math.h>
 
-int rt_photon_emit(rt_hip_ctx*, int, int64_t, int64_t, float*, int64_t, int64_t*)
+#include "rt_ctx.h"
+#include "rt_trace_dev.h"
+
+namespace {
+
+constexpr int BLOCK = 128;
+inline int nblocks(int64_t n, int b) { return (int)((n + b - 1) / b); }
+
+// ---- counter RNG (identical to oracle/rt_oracle.cpp: struct Rng, mode 1) -------------------------
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x)
 {
-	rt_set_error("photon emission not built yet");
-	return RT_HIP_ERR_STATE;
+	x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+	return x;
 }
-int rt_photon_build_grid(rt_hip_ctx*, const float*, int64_t)
+struct Rng {
+	uint32_t seed_lo, seed_hi, index, counter;
+	__device__ __forceinline__ int next()  // 31-bit draw, the range of libc rand()
+	{
+		uint32_t h = lowbias32(index ^ seed_lo);
+		h = lowbias32(h + 0x9E3779B9U * (counter + 1u) + seed_hi);
+		h = lowbias32(h ^ (counter * 0x85EBCA6BU));
+		++counter;
+		return (int)(h >> 1);
+	}
+};
+
+struct PhotonRec {  // 9 floats, the layout of the C ABI
+	float p[3], e[3], d[3];
+};
+
+__global__ __launch_bounds__(BLOCK) void k_photon_emit(SceneView sv, int per_light, int64_t first, int64_t count,
+                                                       uint32_t seed_lo, uint32_t seed_hi, float max_dist0,
+                                                       float absorb, PhotonRec* __restrict__ tmp,
+                                                       uint32_t* __restrict__ miss_digit)
 {
-	rt_set_error("photon grid not built yet");
-	return RT_HIP_ERR_STATE;
+	extern __shared__ __attribute__((aligned(16))) int smem[];
+	int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (k >= count) return;
+	int64_t idx = first + k;
+	int light = (int)(idx / per_light);
+	Rng rng;
+	rng.seed_lo = seed_lo; rng.seed_hi = seed_hi; rng.index = (uint32_t)idx; rng.counter = 0;
+	const float rmax_2 = 1073741824.0f;   // float(RAND_MAX / 2.0)   rt_photon_map.cpp:20,93
+	const float rand_max = 2147483648.0f; // (float)RAND_MAX
+	f3 dir;
+	// generate(): dir in [-1,1]^2 x [-1,0], accepted when |dir|^2 <= 1, NOT normalised (:99-104)
+	for (;;) {
+		dir.x = (float)rng.next() / rmax_2 - 1.0f;
+		dir.y = (float)rng.next() / rmax_2 - 1.0f;
+		dir.z = (float)(-rng.next()) / rand_max;
+		if (!(dot3(dir, dir) > 1.0f)) break;
+	}
+	f3 color = ld3(sv.lights[light].color);
+	f3 energy = div3(color * 5.0f, (float)per_light);  // 5*light->color/count (:97)
+	f3 origin = ld3(sv.lights[light].position);
+	float max_dist = max_dist0;
+	bool stored = false;
+	PhotonRec out;
+	// emit_photon(): `pass++` hands the OLD value down, so every level runs with pass == 0 (:66)
+	for (int depth = 0; depth < (1 << 20); ++depth) {
+		Hit best;
+		scene_trace<false>(sv, origin, dir, best, smem + threadIdx.x, BLOCK);
+		if (best.prim == RT_MISS) break;
+		const TriPos tp = sv.tri_pos[best.prim];
+		const TriAttr ta = sv.tri_attr[best.prim];
+		f3 pos = bary3(best.u, best.v, mk3(tp.p0.x, tp.p0.y, tp.p0.z), mk3(tp.p1.x, tp.p1.y, tp.p1.z), mk3(tp.p2.x, tp.p2.y, tp.p2.z));
+		f3 nrm = normalized3(bary3(best.u, best.v, ld3(ta.n0), ld3(ta.n1), ld3(ta.n2)));
+		float dist = norm3(pos - origin);
+		if (dist > max_dist) break;
+		if ((float)rng.next() / rand_max < absorb) {
+			st3(out.p, pos); st3(out.e, energy); st3(out.d, dir);
+			stored = true;
+			break;
+		}
+		origin = pos;
+		f3 nd = mk3(1.0f, 1.0f, 1.0f);
+		int guard = 0;
+		while ((dot3(nd, nd) > 1.0f || dot3(nd, nrm) < 0.0f) && guard < (1 << 22)) {
+			nd.x = (float)rng.next() / rmax_2 - 1.0f;
+			nd.y = (float)rng.next() / rmax_2 - 1.0f;
+			nd.z = (float)rng.next() / rmax_2 - 1.0f;
+			++guard;
+		}
+		dir = nd;
+		int mat = __float_as_int(tp.p0.w);
+		energy = ld3(sv.materials[mat].diffuse) * (norm3(energy) / 255.0f);  // (:63)
+		max_dist = max_dist - dist;
+	}
+	miss_digit[k] = stored ? 0u : 1u;
+	if (stored) tmp[k] = out;
 }
-int rt_photon_gather(rt_hip_ctx*, const float*, const float*, int, int, float, float*)
+
+__global__ __launch_bounds__(256) void k_photon_compact(const PhotonRec* __restrict__ tmp,
+                                                        const uint32_t* __restrict__ digit,
+                                                        const uint32_t* __restrict__ dest, int64_t n,
+                                                        PhotonRec* __restrict__ out)
 {
-	rt_set_error("photon gather not built yet");
-	return RT_HIP_ERR_STATE;
+	int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (k < n && digit[k] == 0u) out[dest[k]] = tmp[k];
+}
+
+// ---- grid -------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+	uint32_t u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void k_photon_bounds(const PhotonRec* __restrict__ ph, int64_t n,
+                                                       uint32_t* __restrict__ bounds_ord)
+{
+	__shared__ uint32_t sb[6];
+	if (threadIdx.x < 3) sb[threadIdx.x] = 0xFFFFFFFFu;
+	else if (threadIdx.x < 6) sb[threadIdx.x] = 0u;
+	__syncthreads();
+	int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		for (int k = 0; k < 3; ++k) {
+			uint32_t o = f2ord(ph[i].p[k]);
+			atomicMin(&sb[k], o);
+			atomicMax(&sb[3 + k], o);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) atomicMin(&bounds_ord[threadIdx.x], sb[threadIdx.x]);
+	else if (threadIdx.x < 6) atomicMax(&bounds_ord[threadIdx.x], sb[threadIdx.x]);
+}
+
+struct GridDesc {
+	float mn[3];
+	float inv_cell;
+	int dim[3];
+	float cell;
+};
+
+__device__ __forceinline__ int cell_coord(float p, float mn, float inv_cell, int dim)
+{
+	int c = (int)floorf((p - mn) * inv_cell);
+	return min(max(c, 0), dim - 1);
+}
+
+__global__ __launch_bounds__(256) void k_photon_cell_keys(const PhotonRec* __restrict__ ph, int64_t n, GridDesc gd,
+                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+	int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	int cx = cell_coord(ph[i].p[0], gd.mn[0], gd.inv_cell, gd.dim[0]);
+	int cy = cell_coord(ph[i].p[1], gd.mn[1], gd.inv_cell, gd.dim[1]);
+	int cz = cell_coord(ph[i].p[2], gd.mn[2], gd.inv_cell, gd.dim[2]);
+	keys[i] = (uint64_t)((cz * gd.dim[1] + cy) * gd.dim[0] + cx);
+	vals[i] = (uint32_t)i;
+}
+
+// sorted[s] = photons[order[s]] split into a 16-byte position record and a 32-byte payload
+__global__ __launch_bounds__(256) void k_photon_permute(const PhotonRec* __restrict__ ph,
+                                                        const uint32_t* __restrict__ order,
+                                                        const uint64_t* __restrict__ keys, int64_t n, int ncells,
+                                                        float4* __restrict__ pos, float4* __restrict__ payload,
+                                                        uint32_t* __restrict__ cell_start)
+{
+	int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (s >= n) return;
+	const PhotonRec r = ph[order[s]];
+	pos[s] = make_float4(r.p[0], r.p[1], r.p[2], __uint_as_float(order[s]));
+	payload[2 * s] = make_float4(r.e[0], r.e[1], r.e[2], r.d[0]);
+	payload[2 * s + 1] = make_float4(r.d[1], r.d[2], 0.0f, 0.0f);
+	// cell_start[c] = first sorted slot of cell c; filled for every cell in (prev_cell, this_cell]
+	uint32_t c = (uint32_t)keys[s];
+	uint32_t prev = (s == 0) ? 0xFFFFFFFFu : (uint32_t)keys[s - 1];
+	if (s == 0) { for (uint32_t k = 0; k <= c; ++k) cell_start[k] = 0; }
+	else if (prev != c) { for (uint32_t k = prev + 1; k <= c; ++k) cell_start[k] = (uint32_t)s; }
+	if (s == n - 1) { for (uint32_t k = c + 1; k <= (uint32_t)ncells; ++k) cell_start[k] = (uint32_t)n; }
+}
+
+// ---- gather -------------------------------------------------------------------------------------
+struct GatherConst {
+	float alpha, beta, e, gauss_denom, two_pi;
+};
+
+template <typename F>
+__device__ __forceinline__ void for_each_neighbour(const GridDesc& gd, const uint32_t* __restrict__ cell_start,
+                                                   const float4* __restrict__ pos, f3 P, int range, F f)
+{
+	int cx = (int)floorf((P.x - gd.mn[0]) * gd.inv_cell);
+	int cy = (int)floorf((P.y - gd.mn[1]) * gd.inv_cell);
+	int cz = (int)floorf((P.z - gd.mn[2]) * gd.inv_cell);
+	int x0 = max(cx - range, 0), x1 = min(cx + range, gd.dim[0] - 1);
+	int y0 = max(cy - range, 0), y1 = min(cy + range, gd.dim[1] - 1);
+	int z0 = max(cz - range, 0), z1 = min(cz + range, gd.dim[2] - 1);
+	for (int z = z0; z <= z1; ++z)
+		for (int y = y0; y <= y1; ++y) {
+			// cells along x are contiguous in the sorted array: one span per (y, z) row
+			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
+			if (x0 > x1) continue;
+			uint32_t s0 = cell_start[row + x0], s1 = cell_start[row + x1 + 1];
+			for (uint32_t s = s0; s < s1; ++s) {
+				float4 q = pos[s];
+				f3 d = mk3(q.x, q.y, q.z) - P;
+				f(s, dot3(d, d));
+			}
+		}
+}
+
+__global__ __launch_bounds__(256) void k_photon_gather(GridDesc gd, const uint32_t* __restrict__ cell_start,
+                                                       const float4* __restrict__ pos,
+                                                       const float4* __restrict__ payload, int64_t nph,
+                                                       const float* __restrict__ qpos, const float* __restrict__ qnrm,
+                                                       int npts, int count, float radius, int range, GatherConst gc,
+                                                       float* __restrict__ rgb)
+{
+	int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= npts) return;
+	f3 P = ld3(qpos + 3 * (size_t)i), N = ld3(qnrm + 3 * (size_t)i);
+	const float r2 = radius * radius;
+	// pass 1: candidates and max_dist2 over ALL of them (:159-169)
+	int nc = 0;
+	float max_dist2 = 0.0f;
+	if (nph > 0)
+		for_each_neighbour(gd, cell_start, pos, P, range, [&](uint32_t, float l2) {
+			if (l2 < r2) { ++nc; if (l2 > max_dist2) max_dist2 = l2; }
+		});
+	// threshold of the `count` nearest: smallest bit pattern tau with #(l2 <= tau) >= count
+	uint32_t tau = 0xFFFFFFFFu;
+	int take_equal = 0x7fffffff;
+	if (nc > count) {
+		uint32_t lo = 0u, hi = __float_as_uint(r2);  // l2 < r2, so bits(l2) < bits(r2)
+		while (lo < hi) {
+			uint32_t mid = lo + ((hi - lo) >> 1);
+			int c = 0;
+			for_each_neighbour(gd, cell_start, pos, P, range, [&](uint32_t, float l2) {
+				if (l2 < r2 && __float_as_uint(l2) <= mid) ++c;
+			});
+			if (c >= count) hi = mid; else lo = mid + 1;
+		}
+		tau = lo;
+		int less = 0;
+		for_each_neighbour(gd, cell_start, pos, P, range, [&](uint32_t, float l2) {
+			if (l2 < r2 && __float_as_uint(l2) < tau) ++less;
+		});
+		take_equal = count - less;
+	}
+	// pass 3: weighted sum over the selected photons (:178-197)
+	f3 result = mk3(0, 0, 0);
+	if (nc > 0) {
+		const float denom2 = 2.0f * max_dist2;
+		for_each_neighbour(gd, cell_start, pos, P, range, [&](uint32_t s, float l2) {
+			if (!(l2 < r2)) return;
+			uint32_t b = __float_as_uint(l2);
+			bool sel = b < tau;
+			if (!sel && b == tau && take_equal > 0) { sel = true; --take_equal; }
+			if (!sel) return;
+			float w = 1.0f - powf(gc.e, -gc.beta * (l2 / denom2));
+			w *= gc.gauss_denom;
+			w = gc.alpha * (1.0f - w);
+			float4 a = payload[2 * (size_t)s], c = payload[2 * (size_t)s + 1];
+			f3 energy = mk3(a.x, a.y, a.z), dir = mk3(a.w, c.x, c.y);
+			float brdf = dot3(N, neg3(dir));
+			brdf = fminf(fmaxf(brdf, 0.0f), 1.0f);
+			result = result + (energy * brdf) * w;
+		});
+	}
+	// result / (2*PI*max_dist2): 0 * (1/0) = NaN when nothing is in range, as the reference (:204)
+	result = div3(result, gc.two_pi * max_dist2);
+	st3(rgb + 3 * (size_t)i, result);
+}
+
+float ord2f(uint32_t o)
+{
+	uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+	float f;
+	memcpy(&f, &u, 4);
+	return f;
+}
+
+}  // namespace
+
+int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count, float* d_out, int64_t capacity,
+                   int64_t* out_stored)
+{
+	*out_stored = 0;
+	if (count == 0) return RT_HIP_OK;
+	SceneView sv = rt_scene_view(ctx);
+	if (ctx->cfg.geometry != RT_HIP_TRIANGLES) { rt_set_error("photon emission needs triangle geometry"); return RT_HIP_ERR_STATE; }
+	int64_t total = (int64_t)per_light * sv.num_lights;
+	if (first + count > total) { rt_set_error("photon range [%lld,%lld) exceeds lights x per_light = %lld", (long long)first, (long long)(first + count), (long long)total); return RT_HIP_ERR_ARG; }
+	if (count > 0x7FFFFFF0ll) { rt_set_error("more than 2^31 photons per call"); return RT_HIP_ERR_LIMIT; }
+	(void)capacity;
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_photon_tmp.reserve((size_t)count * sizeof(PhotonRec)));
+	RT_CHECK(ctx->d_keys.reserve((size_t)count * 4));
+	RT_CHECK(ctx->d_rank.reserve((size_t)count * 4));
+	RT_CHECK(ctx->d_counts.reserve(2 * 256 * 4));
+	uint32_t* digit = ctx->d_keys.as<uint32_t>();
+	uint32_t* dest = ctx->d_rank.as<uint32_t>();
+	uint32_t* totals = ctx->d_counts.as<uint32_t>();
+	size_t lds = sv.use_bvh ? (size_t)sv.stack_depth * BLOCK * sizeof(int) : 0;
+	hipLaunchKernelGGL(k_photon_emit, dim3(nblocks(count, BLOCK)), dim3(BLOCK), lds, st, sv, per_light, first, count,
+	                   (uint32_t)ctx->cfg.seed, (uint32_t)(ctx->cfg.seed >> 32), ctx->cfg.photon_max_dist,
+	                   ctx->cfg.photon_absorb, ctx->d_photon_tmp.as<PhotonRec>(), digit);
+	RT_HIP_CHECK(hipGetLastError());
+	// digit array is clobbered by multisplit's scratch? no: multisplit reads digit, writes dest/hist only
+	RT_CHECK(rt_multisplit256(ctx, digit, (int)count, dest, totals));
+	hipLaunchKernelGGL(k_photon_compact, dim3(nblocks(count, 256)), dim3(256), 0, st, ctx->d_photon_tmp.as<PhotonRec>(),
+	                   digit, dest, count, (PhotonRec*)d_out);
+	RT_HIP_CHECK(hipGetLastError());
+	uint32_t stored = 0;
+	RT_HIP_CHECK(hipMemcpyAsync(&stored, totals, 4, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	*out_stored = stored;
+	return RT_HIP_OK;
+}
+
+int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
+{
+	hipStream_t st = ctx->stream;
+	ctx->num_photons = 0;
+	if (n > 0x7FFFFFF0ll) { rt_set_error("more than 2^31 photons"); return RT_HIP_ERR_LIMIT; }
+	if (n == 0) return RT_HIP_OK;
+	const PhotonRec* ph = (const PhotonRec*)d_photons;
+	RT_CHECK(ctx->d_bounds.reserve(64));
+	uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_bounds.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_photon_bounds, dim3(nblocks(n, 256)), dim3(256), 0, st, ph, n, ctx->d_bounds.as<uint32_t>());
+	uint32_t ob[6];
+	RT_HIP_CHECK(hipMemcpyAsync(ob, ctx->d_bounds.p, sizeof(ob), hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	float mn[3], mx[3];
+	for (int k = 0; k < 3; ++k) { mn[k] = ord2f(ob[k]); mx[k] = ord2f(ob[3 + k]); }
+	// cell = photon_radius, enlarged until the grid has at most 2^22 cells
+	float cell = ctx->cfg.photon_radius > 0.0f ? ctx->cfg.photon_radius : 1.0f;
+	int dim[3];
+	for (;;) {
+		double cells = 1;
+		for (int k = 0; k < 3; ++k) {
+			dim[k] = std::max(1, (int)std::floor((mx[k] - mn[k]) / cell) + 1);
+			cells *= dim[k];
+		}
+		if (cells <= (double)(1 << 22)) break;
+		cell *= 1.5f;
+	}
+	int ncells = dim[0] * dim[1] * dim[2];
+	GridDesc gd;
+	for (int k = 0; k < 3; ++k) { gd.mn[k] = mn[k]; gd.dim[k] = dim[k]; ctx->photon_grid_min[k] = mn[k]; ctx->photon_grid_dim[k] = dim[k]; }
+	gd.cell = cell; gd.inv_cell = 1.0f / cell;
+	ctx->photon_cell = cell;
+
+	RT_CHECK(ctx->d_morton.reserve((size_t)n * 8));
+	RT_CHECK(ctx->d_morton_tmp.reserve((size_t)n * 8));
+	RT_CHECK(ctx->d_order.reserve((size_t)n * 4));
+	RT_CHECK(ctx->d_order_tmp.reserve((size_t)n * 4));
+	uint64_t* keys = ctx->d_morton.as<uint64_t>();
+	uint32_t* order = ctx->d_order.as<uint32_t>();
+	hipLaunchKernelGGL(k_photon_cell_keys, dim3(nblocks(n, 256)), dim3(256), 0, st, ph, n, gd, keys, order);
+	RT_HIP_CHECK(hipGetLastError());
+	int bits = 1;
+	while ((1ll << bits) < ncells) ++bits;
+	RT_CHECK(rt_radix_sort_pairs64(ctx, keys, ctx->d_morton_tmp.as<uint64_t>(), order, ctx->d_order_tmp.as<uint32_t>(), (int)n, bits));
+	RT_CHECK(ctx->d_photons.reserve((size_t)n * 16));
+	RT_CHECK(ctx->d_photon_sorted.reserve((size_t)n * 32));
+	RT_CHECK(ctx->d_cell_start.reserve((size_t)(ncells + 2) * 4));
+	hipLaunchKernelGGL(k_photon_permute, dim3(nblocks(n, 256)), dim3(256), 0, st, ph, order, keys, n, ncells,
+	                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->d_cell_start.as<uint32_t>());
+	RT_HIP_CHECK(hipGetLastError());
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	ctx->num_photons = n;
+	return RT_HIP_OK;
+}
+
+int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int npts, int count, float radius,
+                     float* d_rgb)
+{
+	if (npts <= 0) return RT_HIP_OK;
+	GridDesc gd;
+	for (int k = 0; k < 3; ++k) { gd.mn[k] = ctx->photon_grid_min[k]; gd.dim[k] = ctx->num_photons ? ctx->photon_grid_dim[k] : 1; }
+	gd.cell = ctx->photon_cell; gd.inv_cell = 1.0f / ctx->photon_cell;
+	int range = (int)std::ceil(radius / ctx->photon_cell);
+	if (range < 1) range = 1;
+	// rt_photon_map.cpp:13-18, evaluated in float exactly as the reference's file-scope constants
+	const float ALPHA = 0.918, BETA = 1.953, PI = 3.141592653589793, E = 2.718281828459045;
+	GatherConst gc;
+	gc.alpha = ALPHA; gc.beta = BETA; gc.e = E;
+	gc.gauss_denom = 1 / (1 - powf(E, -BETA));
+	gc.two_pi = 2 * PI;
+	hipLaunchKernelGGL(k_photon_gather, dim3(nblocks(npts, 256)), dim3(256), 0, ctx->stream, gd,
+	                   ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(),
+	                   ctx->num_photons, d_pos, d_nrm, npts, count, radius, range, gc, d_rgb);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
 }
