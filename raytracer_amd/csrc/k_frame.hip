@@ -18,14 +18,14 @@ constexpr int TRACE_BLOCK = 128;
 inline int nblocks(int64_t n, int b) { return (int)((n + b - 1) / b); }
 
 // Resolved hit: what IAccel::intersect leaves in the Ray plus the material.
-struct HitInfo {
+struct __attribute__((aligned(16))) HitInfo {
 	float pos[3];
 	int material;  // -1 = miss
 	float nrm[3];
 	float pad;
 };
 
-struct NodeGeo {   // 48 B
+struct __attribute__((aligned(16))) NodeGeo {   // 48 B
 	float V[3];
 	int parent;    // level 0: pixel index; deeper: index of the parent node in the previous level
 	float N[3];
@@ -33,7 +33,7 @@ struct NodeGeo {   // 48 B
 	float I[3];
 	int branch;    // 0 reflection child, 1 refraction child
 };
-struct NodeShade { // 48 B
+struct __attribute__((aligned(16))) NodeShade { // 48 B
 	float F[3];    // shadow * light
 	float pad0;
 	float refc[3]; // colour returned by the reflection child (0 if none)
@@ -41,6 +41,28 @@ struct NodeShade { // 48 B
 	float refrc[3];
 	float pad2;
 };
+
+// Block-level stream compaction: destination slot for every lane whose flag is set, with ONE
+// global atomic per 1024-thread workgroup (a single word sustains only ~88 returning atomics/us
+// on MI355X, so one atomic per wave made these kernels atomic-bound).  Every thread of the
+// workgroup must call it.  Order inside a workgroup is lane order; across workgroups arrival order.
+constexpr int CBLOCK = 1024;
+__device__ __forceinline__ int block_compact_slot(bool flag, int* __restrict__ counter)
+{
+	__shared__ int s_wave[CBLOCK / 64];
+	__shared__ int s_base;
+	const uint64_t m = __ballot(flag);
+	const int wave = (int)(threadIdx.x >> 6);
+	if ((threadIdx.x & 63) == 0) s_wave[wave] = (int)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int tot = 0;
+		for (int w = 0; w < CBLOCK / 64; ++w) { int c = s_wave[w]; s_wave[w] = tot; tot += c; }
+		s_base = tot ? atomicAdd(counter, tot) : 0;
+	}
+	__syncthreads();
+	return s_base + s_wave[wave] + (int)__popcll(m & lanemask_lt());
+}
 
 // ---- ray generation ------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_reflect_raygen(const float* __restrict__ pos, const float* __restrict__ nrm,
@@ -232,47 +254,50 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
                                                                  float* __restrict__ pos_rgb)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
-	int i = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-	if (i >= w * h) return;
-	int x = i % w, y = i / w;
-	float aspect = float(w) / h;
-	float dirX = (float)(2 * ((x + 0.5) / w) - 1);
-	float dirY = (float)(2 * ((y + 0.5) / h) - 1);
-	dirX *= aspect;
-	f3 D = mk3(dirX * tanfov, dirY * tanfov, -1.0f);
-	f3 O = mk3(0, 0, 0);
-	float alpha = 0.0f;
-	f3 P = mk3(0, 0, 0), N = mk3(0, 0, 1);
-	if (sv.num_spheres > 0 && sv.num_tris == 0) {
-		// nearest sphere along the TRUE ray (the G-buffer producer stands in for the rasterizer,
-		// it does not inherit AccelSpheres::intersect's origin quirk)
-		float bestd = __builtin_inff();
-		f3 Dn = normalized3(D);
-		for (int k = 0; k < sv.num_spheres; ++k) {
-			f3 X, Nn;
-			if (sphere_test_ref(sv.spheres[k], O, Dn, X, Nn)) {
-				float d2 = dot3(X, X);
-				if (d2 < bestd) { bestd = d2; P = X; N = Nn; alpha = (float)(sv.num_materials - sv.num_spheres + k + 1); }
+	const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+	const int gsize = gridDim.x * TRACE_BLOCK;
+	int* spill = sv.spill + gtid;
+	for (int i = gtid; i < w * h; i += gsize) {
+		int x = i % w, y = i / w;
+		float aspect = float(w) / h;
+		float dirX = (float)(2 * ((x + 0.5) / w) - 1);
+		float dirY = (float)(2 * ((y + 0.5) / h) - 1);
+		dirX *= aspect;
+		f3 D = mk3(dirX * tanfov, dirY * tanfov, -1.0f);
+		f3 O = mk3(0, 0, 0);
+		float alpha = 0.0f;
+		f3 P = mk3(0, 0, 0), N = mk3(0, 0, 1);
+		if (sv.num_spheres > 0 && sv.num_tris == 0) {
+			// nearest sphere along the TRUE ray (the G-buffer producer stands in for the rasterizer,
+			// it does not inherit AccelSpheres::intersect's origin quirk)
+			float bestd = __builtin_inff();
+			f3 Dn = normalized3(D);
+			for (int k = 0; k < sv.num_spheres; ++k) {
+				f3 X, Nn;
+				if (sphere_test_ref(sv.spheres[k], O, Dn, X, Nn)) {
+					float d2 = dot3(X, X);
+					if (d2 < bestd) { bestd = d2; P = X; N = Nn; alpha = (float)(sv.num_materials - sv.num_spheres + k + 1); }
+				}
+			}
+		} else {
+			Hit best;
+			scene_trace<false>(sv, O, D, best, smem + threadIdx.x, TRACE_BLOCK, spill);
+			if (best.prim != RT_MISS) {
+				HitInfo hi;
+				resolve_tri(sv, best, hi, nullptr);
+				P = ld3(hi.pos); N = ld3(hi.nrm);
+				alpha = (float)(hi.material + 1);
 			}
 		}
-	} else {
-		Hit best;
-		scene_trace<false>(sv, O, D, best, smem + threadIdx.x, TRACE_BLOCK);
-		if (best.prim != RT_MISS) {
-			HitInfo hi;
-			resolve_tri(sv, best, hi, nullptr);
-			P = ld3(hi.pos); N = ld3(hi.nrm);
-			alpha = (float)(hi.material + 1);
-		}
+		f3 nn = normalized3(N);
+		nrm_rgba[4 * (size_t)i + 0] = unorm16(nn.x * 0.5f + 0.5f);
+		nrm_rgba[4 * (size_t)i + 1] = unorm16(nn.y * 0.5f + 0.5f);
+		nrm_rgba[4 * (size_t)i + 2] = unorm16(nn.z * 0.5f + 0.5f);
+		nrm_rgba[4 * (size_t)i + 3] = alpha;
+		pos_rgb[3 * (size_t)i + 0] = half_round(P.x);
+		pos_rgb[3 * (size_t)i + 1] = half_round(P.y);
+		pos_rgb[3 * (size_t)i + 2] = half_round(P.z);
 	}
-	f3 nn = normalized3(N);
-	nrm_rgba[4 * (size_t)i + 0] = unorm16(nn.x * 0.5f + 0.5f);
-	nrm_rgba[4 * (size_t)i + 1] = unorm16(nn.y * 0.5f + 0.5f);
-	nrm_rgba[4 * (size_t)i + 2] = unorm16(nn.z * 0.5f + 0.5f);
-	nrm_rgba[4 * (size_t)i + 3] = alpha;
-	pos_rgb[3 * (size_t)i + 0] = half_round(P.x);
-	pos_rgb[3 * (size_t)i + 1] = half_round(P.y);
-	pos_rgb[3 * (size_t)i + 2] = half_round(P.z);
 }
 
 // ---- Gen-1 shade() wavefront ---------------------------------------------------------------------
@@ -287,12 +312,12 @@ __device__ __forceinline__ bool tile_is_mine(int pixel, int w, int tile, int ran
 	return ((tx + ty) % nranks) == rank;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_init_nodes(const float* __restrict__ pos_rgb,
+__global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__ pos_rgb,
                                                       const float* __restrict__ nrm_rgba, int w, int h, int tile,
                                                       int rank, int nranks, int num_materials,
                                                       NodeGeo* __restrict__ geo, int* __restrict__ active_count)
 {
-	int i = blockIdx.x * BLOCK + threadIdx.x;
+	int i = blockIdx.x * CBLOCK + threadIdx.x;
 	bool active = false;
 	if (i < w * h) {
 	NodeGeo g;
@@ -312,8 +337,14 @@ __global__ __launch_bounds__(BLOCK) void k_init_nodes(const float* __restrict__ 
 	geo[i] = g;
 	active = mat >= 0;
 	}
+	// one counter add per workgroup
+	__shared__ int s_cnt;
+	if (threadIdx.x == 0) s_cnt = 0;
+	__syncthreads();
 	uint64_t m = __ballot(active);
-	if (m && lane_id() == (int)__builtin_ctzll(m)) atomicAdd(active_count, (int)__popcll(m));
+	if (m && (threadIdx.x & 63) == 0) atomicAdd(&s_cnt, (int)__popcll(m));
+	__syncthreads();
+	if (threadIdx.x == 0 && s_cnt) atomicAdd(active_count, s_cnt);
 }
 
 // Shadow rays: one lane per (light, node); lanes of a wave share the light, so the rays of a
@@ -325,39 +356,42 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const Node
 {
 	if (shadow_t_max > 0.0f) sv.tp.t_max = shadow_t_max;
 	extern __shared__ __attribute__((aligned(16))) int smem[];
-	int64_t idx = (int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
-	uint32_t cn = 0, ct = 0;
-	bool active = false;
-	if (idx < (int64_t)n * sv.num_lights) {
+	const int64_t gtid = (int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
+	const int64_t gsize = (int64_t)gridDim.x * TRACE_BLOCK;
+	const int64_t total = (int64_t)n * sv.num_lights;
+	int* spill = sv.spill + gtid;
+	uint32_t cn = 0, ct = 0, rays = 0;
+	for (int64_t idx = gtid; idx < total; idx += gsize) {
 		int light = (int)(idx / n), i = (int)(idx % n);
 		const NodeGeo g = geo[i];
-		if (g.material >= 0) {
-			active = true;
-			f3 V = ld3(g.V), N = ld3(g.N);
-			f3 L = ld3(sv.lights[light].position) - V;
-			f3 O = V + N * 0.1f;  // bias = 0.1 (rt_raytracer.cpp:79,112)
-			bool blocked;
-			if (sv.num_spheres > 0 && sv.num_tris == 0) {
-				blocked = false;
-				f3 X, Nn;
-				for (int k = 0; k < sv.num_spheres; ++k)
-					if (sphere_test_ref(sv.spheres[k], L, L, X, Nn)) { blocked = true; break; }
-			} else if (sv.use_bvh) {
-				Hit best;
-				blocked = bvh_trace<true, CENSUS>(sv, O, L, best, smem + threadIdx.x, TRACE_BLOCK, cn, ct);
-			} else {
-				Hit best;
-				blocked = brute_trace<true>(sv, O, L, best);
-			}
-			// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116)
-			if (blocked && 0.0f < norm3(L)) atomicOr(&occl[i], 1u << light);
+		if (g.material < 0) continue;
+		++rays;
+		f3 V = ld3(g.V), N = ld3(g.N);
+		f3 L = ld3(sv.lights[light].position) - V;
+		f3 O = V + N * 0.1f;  // bias = 0.1 (rt_raytracer.cpp:79,112)
+		bool blocked;
+		if (sv.num_spheres > 0 && sv.num_tris == 0) {
+			blocked = false;
+			f3 X, Nn;
+			for (int k = 0; k < sv.num_spheres; ++k)
+				if (sphere_test_ref(sv.spheres[k], L, L, X, Nn)) { blocked = true; break; }
+		} else if (sv.use_bvh) {
+			Hit best;
+			uint32_t a = 0, b = 0;
+			blocked = bvh_trace<true, CENSUS>(sv, O, L, best, smem + threadIdx.x, TRACE_BLOCK, spill, a, b);
+			cn += a; ct += b;
+		} else {
+			Hit best;
+			blocked = brute_trace<true>(sv, O, L, best);
 		}
+		// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116)
+		if (blocked && 0.0f < norm3(L)) atomicOr(&occl[i], 1u << light);
 	}
-	if (CENSUS && census) census_add(census, cn, ct, active);
+	if (CENSUS && census) census_add(census, cn, ct, rays);
 }
 
 // Per node: lambert / shadow -> F, and the reflection ray if this level may recurse.
-__global__ __launch_bounds__(BLOCK) void k_light_spawn_reflect(SceneView sv, const NodeGeo* __restrict__ geo,
+__global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, const NodeGeo* __restrict__ geo,
                                                                NodeShade* __restrict__ shade, int n,
                                                                const unsigned int* __restrict__ occl,
                                                                const float* __restrict__ photon_rgb, int do_shadows,
@@ -365,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void k_light_spawn_reflect(SceneView sv, con
                                                                float* __restrict__ q_org, float* __restrict__ q_dir,
                                                                int* __restrict__ q_parent, int* __restrict__ q_count)
 {
-	int i = blockIdx.x * BLOCK + threadIdx.x;
+	int i = blockIdx.x * CBLOCK + threadIdx.x;
 	bool emit = false;
 	f3 V = mk3(0, 0, 0), R = mk3(0, 0, 0);
 	if (i < n) {
@@ -402,29 +436,22 @@ __global__ __launch_bounds__(BLOCK) void k_light_spawn_reflect(SceneView sv, con
 		}
 		shade[i] = s;
 	}
-	// wave-level compaction: one atomic per wave
-	uint64_t m = __ballot(emit);
-	if (m) {
-		int lane = lane_id();
-		int base = 0;
-		if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(q_count, (int)__popcll(m));
-		base = __shfl(base, (int)__builtin_ctzll(m));
-		if (emit) {
-			int s = base + (int)__popcll(m & lanemask_lt());
-			st3(q_org + 3 * (size_t)s, V);
-			st3(q_dir + 3 * (size_t)s, R);
-			q_parent[s] = i;
-		}
+	// wave ballots + one atomic per workgroup
+	int slot = block_compact_slot(emit, q_count);
+	if (emit) {
+		st3(q_org + 3 * (size_t)slot, V);
+		st3(q_dir + 3 * (size_t)slot, R);
+		q_parent[slot] = i;
 	}
 }
 
 // Refraction spawn: gated by the (possibly overwritten, quirk Q9) material.
-__global__ __launch_bounds__(BLOCK) void k_spawn_refract(SceneView sv, const NodeGeo* __restrict__ geo, int n,
+__global__ __launch_bounds__(CBLOCK) void k_spawn_refract(SceneView sv, const NodeGeo* __restrict__ geo, int n,
                                                          const int* __restrict__ gate, float* __restrict__ q_org,
                                                          float* __restrict__ q_dir, int* __restrict__ q_parent,
                                                          int* __restrict__ q_count)
 {
-	int i = blockIdx.x * BLOCK + threadIdx.x;
+	int i = blockIdx.x * CBLOCK + threadIdx.x;
 	bool emit = false;
 	f3 V = mk3(0, 0, 0), T = mk3(0, 0, 0);
 	if (i < n) {
@@ -445,18 +472,11 @@ __global__ __launch_bounds__(BLOCK) void k_spawn_refract(SceneView sv, const Nod
 			}
 		}
 	}
-	uint64_t m = __ballot(emit);
-	if (m) {
-		int lane = lane_id();
-		int base = 0;
-		if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(q_count, (int)__popcll(m));
-		base = __shfl(base, (int)__builtin_ctzll(m));
-		if (emit) {
-			int s = base + (int)__popcll(m & lanemask_lt());
-			st3(q_org + 3 * (size_t)s, V);
-			st3(q_dir + 3 * (size_t)s, T);
-			q_parent[s] = i;
-		}
+	int slot = block_compact_slot(emit, q_count);
+	if (emit) {
+		st3(q_org + 3 * (size_t)slot, V);
+		st3(q_dir + 3 * (size_t)slot, T);
+		q_parent[slot] = i;
 	}
 }
 
@@ -481,12 +501,12 @@ __global__ __launch_bounds__(BLOCK) void k_queue_sphere_hits(SceneView sv, const
 }
 
 // Turn the resolved hits of a queue into child nodes of the next level.
-__global__ __launch_bounds__(BLOCK) void k_make_children(const HitInfo* __restrict__ hi, const float* __restrict__ q_dir,
+__global__ __launch_bounds__(CBLOCK) void k_make_children(const HitInfo* __restrict__ hi, const float* __restrict__ q_dir,
                                                          const int* __restrict__ q_parent, int nq, int branch,
                                                          int* __restrict__ gate, NodeGeo* __restrict__ child_geo,
                                                          int* __restrict__ child_count)
 {
-	int i = blockIdx.x * BLOCK + threadIdx.x;
+	int i = blockIdx.x * CBLOCK + threadIdx.x;
 	bool hit = false;
 	HitInfo h;
 	if (i < nq) {
@@ -494,21 +514,14 @@ __global__ __launch_bounds__(BLOCK) void k_make_children(const HitInfo* __restri
 		hit = h.material >= 0;
 		if (hit && branch == 0) gate[q_parent[i]] = h.material;  // Q9: reflection hit overwrites `material`
 	}
-	uint64_t m = __ballot(hit);
-	if (m) {
-		int lane = lane_id();
-		int base = 0;
-		if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(child_count, (int)__popcll(m));
-		base = __shfl(base, (int)__builtin_ctzll(m));
-		if (hit) {
-			int s = base + (int)__popcll(m & lanemask_lt());
-			NodeGeo g;
-			for (int k = 0; k < 3; ++k) { g.V[k] = h.pos[k]; g.N[k] = h.nrm[k]; g.I[k] = q_dir[3 * (size_t)i + k]; }
-			g.parent = q_parent[i];
-			g.material = h.material;
-			g.branch = branch;
-			child_geo[s] = g;
-		}
+	int slot = block_compact_slot(hit, child_count);
+	if (hit) {
+		NodeGeo g;
+		for (int k = 0; k < 3; ++k) { g.V[k] = h.pos[k]; g.N[k] = h.nrm[k]; g.I[k] = q_dir[3 * (size_t)i + k]; }
+		g.parent = q_parent[i];
+		g.material = h.material;
+		g.branch = branch;
+		child_geo[slot] = g;
 	}
 }
 
@@ -708,8 +721,8 @@ int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgb
 {
 	SceneView sv = rt_scene_view(ctx);
 	float tanfov = tanf(fov);  // Camera::setFOV (data/camera.cpp:41-44)
-	size_t lds = sv.use_bvh ? (size_t)sv.stack_depth * TRACE_BLOCK * sizeof(int) : 0;
-	hipLaunchKernelGGL(k_primary_gbuffer, dim3(nblocks((int64_t)w * h, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, ctx->stream,
+	size_t lds = rt_trace_lds(sv, TRACE_BLOCK);
+	hipLaunchKernelGGL(k_primary_gbuffer, dim3(rt_trace_blocks(ctx, (int64_t)w * h, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, ctx->stream,
 	                   sv, tanfov, w, h, d_nrm_rgba, d_pos_rgb);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
@@ -767,7 +780,7 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 
 	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
 	RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 64, st));
-	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(npix, BLOCK)), dim3(BLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, tile, rank,
+	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(npix, CBLOCK)), dim3(CBLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, tile, rank,
 	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), qcount + 8);
 	RT_HIP_CHECK(hipGetLastError());
 	int active0 = 0;
@@ -804,14 +817,14 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 			occl = ctx->d_occ.as<unsigned int>();
 			RT_HIP_CHECK(hipMemsetAsync(occl, 0, (size_t)n * 4, st));
 			int64_t total = (int64_t)n * sv.num_lights;
-			size_t lds = sv.use_bvh ? (size_t)sv.stack_depth * TRACE_BLOCK * sizeof(int) : 0;
+			size_t lds = rt_trace_lds(sv, TRACE_BLOCK);
 			RT_CHECK(rt_begin_trace_timing(ctx));
 			unsigned long long* cen = rt_census_ptr(ctx, 1);
 			if (cen)
-				hipLaunchKernelGGL(k_shadow<true>, dim3(nblocks(total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
+				hipLaunchKernelGGL(k_shadow<true>, dim3(rt_trace_blocks(ctx, total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
 				                   ctx->cfg.shadow_t_max, occl, cen);
 			else
-				hipLaunchKernelGGL(k_shadow<false>, dim3(nblocks(total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
+				hipLaunchKernelGGL(k_shadow<false>, dim3(rt_trace_blocks(ctx, total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
 				                   ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_CHECK(rt_end_trace_timing(ctx, 1));
@@ -830,7 +843,7 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 		HitInfo* d_hi = ctx->d_records.as<HitInfo>();
 
 		RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 16, st));
-		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, occl,
+		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, occl,
 		                   photon_rgb, ctx->cfg.do_shadows, recurse ? 1 : 0, gate, q_org, q_dir, q_parent, qcount);
 		RT_HIP_CHECK(hipGetLastError());
 		if (!recurse) break;
@@ -848,13 +861,13 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 		if (nq > 0) {
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
 			rays += nq;
-			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, st, d_hi, q_dir, q_parent, nq, 0,
+			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, nq, 0,
 			                   gate, child_geo, qcount + 1);
 			RT_HIP_CHECK(hipGetLastError());
 		}
 		// refraction, gated after the reflection hits are known (Q9)
 		RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 4, st));
-		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, n, gate, q_org, q_dir,
+		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, gate, q_org, q_dir,
 		                   q_parent, qcount);
 		RT_HIP_CHECK(hipGetLastError());
 		RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
@@ -863,7 +876,7 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 		if (nq > 0) {
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
 			rays += nq;
-			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, st, d_hi, q_dir, q_parent, nq, 1,
+			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, nq, 1,
 			                   gate, child_geo, qcount + 1);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));

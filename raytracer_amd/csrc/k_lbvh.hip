@@ -227,6 +227,10 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 		rt_set_error("LBVH depth %d exceeds the traversal stack limit (96)", depth);
 		return RT_HIP_ERR_LIMIT;
 	}
+	// overflow part of the traversal stacks: entries beyond the LDS-resident ones, one column per
+	// thread of a persistent trace launch
+	int over = depth + 1 - rt_lds_depth();
+	if (over > 0) RT_CHECK(ctx->d_spill.reserve((size_t)over * ctx->max_trace_threads * sizeof(int)));
 	ctx->use_bvh = 1;
 	return RT_HIP_OK;
 }

@@ -50,8 +50,10 @@ __global__ __launch_bounds__(BLOCK) void k_photon_emit(SceneView sv, int per_lig
                                                        uint32_t* __restrict__ miss_digit)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
-	int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-	if (k >= count) return;
+	const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const int64_t gsize = (int64_t)gridDim.x * BLOCK;
+	int* spill = sv.spill + gtid;
+	for (int64_t k = gtid; k < count; k += gsize) {
 	int64_t idx = first + k;
 	int light = (int)(idx / per_light);
 	Rng rng;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_photon_emit(SceneView sv, int per_lig
 	// emit_photon(): `pass++` hands the OLD value down, so every level runs with pass == 0 (:66)
 	for (int depth = 0; depth < (1 << 20); ++depth) {
 		Hit best;
-		scene_trace<false>(sv, origin, dir, best, smem + threadIdx.x, BLOCK);
+		scene_trace<false>(sv, origin, dir, best, smem + threadIdx.x, BLOCK, spill);
 		if (best.prim == RT_MISS) break;
 		const TriPos tp = sv.tri_pos[best.prim];
 		const TriAttr ta = sv.tri_attr[best.prim];
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(BLOCK) void k_photon_emit(SceneView sv, int per_lig
 	}
 	miss_digit[k] = stored ? 0u : 1u;
 	if (stored) tmp[k] = out;
+	}
 }
 
 __global__ __launch_bounds__(256) void k_photon_compact(const PhotonRec* __restrict__ tmp,
@@ -309,8 +312,8 @@ int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count,
 	uint32_t* digit = ctx->d_keys.as<uint32_t>();
 	uint32_t* dest = ctx->d_rank.as<uint32_t>();
 	uint32_t* totals = ctx->d_counts.as<uint32_t>();
-	size_t lds = sv.use_bvh ? (size_t)sv.stack_depth * BLOCK * sizeof(int) : 0;
-	hipLaunchKernelGGL(k_photon_emit, dim3(nblocks(count, BLOCK)), dim3(BLOCK), lds, st, sv, per_light, first, count,
+	size_t lds = rt_trace_lds(sv, BLOCK);
+	hipLaunchKernelGGL(k_photon_emit, dim3(rt_trace_blocks(ctx, count, BLOCK)), dim3(BLOCK), lds, st, sv, per_light, first, count,
 	                   (uint32_t)ctx->cfg.seed, (uint32_t)(ctx->cfg.seed >> 32), ctx->cfg.photon_max_dist,
 	                   ctx->cfg.photon_absorb, ctx->d_photon_tmp.as<PhotonRec>(), digit);
 	RT_HIP_CHECK(hipGetLastError());

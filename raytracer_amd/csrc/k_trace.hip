@@ -55,18 +55,24 @@ __global__ __launch_bounds__(BVH_BLOCK) void k_bvh(SceneView sv, const float* __
                                                    uint8_t* __restrict__ occ, uint32_t* __restrict__ nv,
                                                    uint32_t* __restrict__ nt, unsigned long long* census)
 {
+	// Persistent grid: at most the device's resident-thread capacity, each thread strides over the
+	// rays; its overflow-stack column in HBM is its global thread id.
 	extern __shared__ __attribute__((aligned(16))) int smem[];
-	int i = blockIdx.x * BVH_BLOCK + threadIdx.x;
-	uint32_t cn = 0, ct = 0;
-	if (i < n) {
+	const int gtid = blockIdx.x * BVH_BLOCK + threadIdx.x;
+	const int gsize = gridDim.x * BVH_BLOCK;
+	int* spill = sv.spill + gtid;
+	uint32_t cn = 0, ct = 0, rays = 0;
+	for (int i = gtid; i < n; i += gsize) {
 		f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
 		Hit best;
-		bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, smem + threadIdx.x, BVH_BLOCK, cn, ct);
-		if (CENSUS && nv) { nv[i] = cn; nt[i] = ct; }
+		uint32_t a = 0, b = 0;
+		bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, smem + threadIdx.x, BVH_BLOCK, spill, a, b);
+		if (CENSUS && nv) { nv[i] = a; nt[i] = b; }
+		cn += a; ct += b; ++rays;
 		if (ANY) { if (occ) occ[i] = any ? 1 : 0; }
 		else if (hits) hits[i] = best;
 	}
-	if (CENSUS && census) census_add(census, cn, ct, i < n);
+	if (CENSUS && census) census_add(census, cn, ct, rays);
 }
 
 // ---- spheres ----------------------------------------------------------------------------------
@@ -116,12 +122,12 @@ int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, i
 	RT_CHECK(rt_begin_trace_timing(ctx));
 	unsigned long long* cen = rt_census_ptr(ctx, 0);
 	if (sv.use_bvh && cen) {
-		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
-		hipLaunchKernelGGL((k_bvh<false, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		size_t lds = rt_trace_lds(sv, BVH_BLOCK);
+		hipLaunchKernelGGL((k_bvh<false, true>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
 		                   d_org, d_dir, n, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cen);
 	} else if (sv.use_bvh) {
-		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
-		hipLaunchKernelGGL((k_bvh<false, false>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		size_t lds = rt_trace_lds(sv, BVH_BLOCK);
+		hipLaunchKernelGGL((k_bvh<false, false>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
 		                   d_org, d_dir, n, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
 		                   (unsigned long long*)nullptr);
 	} else {
@@ -141,12 +147,12 @@ int rt_launch_any(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n
 	RT_CHECK(rt_begin_trace_timing(ctx));
 	unsigned long long* cen = rt_census_ptr(ctx, 1);
 	if (sv.use_bvh && cen) {
-		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
-		hipLaunchKernelGGL((k_bvh<true, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		size_t lds = rt_trace_lds(sv, BVH_BLOCK);
+		hipLaunchKernelGGL((k_bvh<true, true>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
 		                   d_org, d_dir, n, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr, cen);
 	} else if (sv.use_bvh) {
-		size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
-		hipLaunchKernelGGL((k_bvh<true, false>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		size_t lds = rt_trace_lds(sv, BVH_BLOCK);
+		hipLaunchKernelGGL((k_bvh<true, false>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
 		                   d_org, d_dir, n, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr,
 		                   (unsigned long long*)nullptr);
 	} else {
@@ -181,12 +187,12 @@ int rt_launch_census(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, in
 		rt_set_error("census needs the LBVH (accel = brute force)");
 		return RT_HIP_ERR_STATE;
 	}
-	size_t lds = (size_t)sv.stack_depth * BVH_BLOCK * sizeof(int);
+	size_t lds = rt_trace_lds(sv, BVH_BLOCK);
 	if (any_hit)
-		hipLaunchKernelGGL((k_bvh<true, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		hipLaunchKernelGGL((k_bvh<true, true>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
 		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt, (unsigned long long*)nullptr);
 	else
-		hipLaunchKernelGGL((k_bvh<false, true>), dim3(nblocks(n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
+		hipLaunchKernelGGL((k_bvh<false, true>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
 		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt, (unsigned long long*)nullptr);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;

@@ -69,6 +69,34 @@ int rt_ensure_pinned(void** p, size_t* cap, size_t bytes)
 	return RT_HIP_OK;
 }
 
+size_t rt_debug_extra_lds()
+{
+	static long v = -1;
+	if (v < 0) { const char* e = getenv("RT_HIP_EXTRA_LDS"); v = e ? atol(e) : 0; }
+	return (size_t)v;
+}
+
+int rt_lds_depth()
+{
+	static int v = -1;
+	if (v < 0) { const char* e = getenv("RT_HIP_LDS_DEPTH"); v = e ? atoi(e) : 12; if (v < 1) v = 1; }
+	return v;
+}
+
+int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block)
+{
+	int64_t need = (work_items + block - 1) / block;
+	static int mult = -1;  // RT_HIP_GRID_MULT: experiments only (values > 1 are unsafe unless nothing spills)
+	if (mult < 0) { const char* e = getenv("RT_HIP_GRID_MULT"); mult = e ? atoi(e) : 1; if (mult < 1) mult = 1; }
+	int64_t cap = std::max<int64_t>(1, (int64_t)ctx->max_trace_threads / block * mult);
+	return (int)std::max<int64_t>(1, std::min(need, cap));
+}
+
+size_t rt_trace_lds(const SceneView& sv, int block)
+{
+	return sv.use_bvh ? (size_t)sv.lds_depth * block * sizeof(int) + rt_debug_extra_lds() : 0;
+}
+
 SceneView rt_scene_view(const rt_hip_ctx* ctx)
 {
 	SceneView sv;
@@ -85,6 +113,9 @@ SceneView rt_scene_view(const rt_hip_ctx* ctx)
 	sv.num_lights = (int)ctx->lights.size();
 	sv.use_bvh = ctx->use_bvh;
 	sv.stack_depth = ctx->bvh_depth + 1;
+	sv.lds_depth = std::min(sv.stack_depth, rt_lds_depth());
+	sv.spill = ctx->d_spill.as<int>();
+	sv.spill_stride = ctx->max_trace_threads;
 	sv.tp.eps_det = ctx->cfg.eps_det;
 	sv.tp.eps_t = ctx->cfg.eps_t;
 	sv.tp.t_max = ctx->cfg.t_max;
@@ -220,6 +251,12 @@ int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out)
 	rt_hip_ctx* ctx = new rt_hip_ctx();
 	ctx->cfg = *cfg;
 	memset(&ctx->stats, 0, sizeof(ctx->stats));
+	{
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
+			ctx->max_trace_threads = prop.multiProcessorCount * prop.maxThreadsPerMultiProcessor;
+		if (ctx->max_trace_threads <= 0) ctx->max_trace_threads = 256 * 2048;
+	}
 	hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
@@ -245,7 +282,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_hits, &ctx->d_occ, &ctx->d_in_a, &ctx->d_in_b, &ctx->d_records, &ctx->d_offsets, &ctx->d_keys,
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
-	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census};
+	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);

@@ -68,6 +68,9 @@ struct SceneView {
 	int num_lights;
 	int use_bvh;      // 0: brute force over `tris`
 	int stack_depth;  // required traversal stack entries (BVH depth + 1)
+	int lds_depth;    // entries [0, lds_depth) of a lane's stack live in LDS, the rest in `spill`
+	int* spill;       // [stack_depth - lds_depth][spill_stride] ints in HBM (nullptr if not needed)
+	int spill_stride; // = maximum number of threads of a trace launch (persistent grid)
 	TraceParams tp;
 };
 
@@ -78,7 +81,8 @@ struct rt_hip_ctx {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;  // pending (profile mode)
 	std::vector<int> trace_event_class;                           // 0 closest, 1 any
 	size_t trace_events_used = 0;
-	DevBuf d_census;                                              // 6 x u64 (census mode)
+	DevBuf d_census, d_spill;
+	int max_trace_threads = 0;                                    // resident-thread capacity of the device                                              // 6 x u64 (census mode)
 
 	std::vector<HostMesh> meshes;
 	std::vector<HostSphere> spheres;
@@ -115,6 +119,12 @@ struct rt_hip_ctx {
 };
 
 SceneView rt_scene_view(const rt_hip_ctx* ctx);
+size_t rt_debug_extra_lds();
+int rt_lds_depth();           // RT_HIP_LDS_DEPTH, default 12
+// Persistent launch shape of the trace kernels: blocks of `block` threads, at most the device's
+// resident-thread capacity in total (the spill stack is sized for exactly that many threads).
+int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block);
+size_t rt_trace_lds(const SceneView& sv, int block);  // RT_HIP_EXTRA_LDS (bytes): occupancy experiments only
 int rt_begin_trace_timing(rt_hip_ctx* ctx);
 int rt_end_trace_timing(rt_hip_ctx* ctx, int cls);
 unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls);  // nullptr unless cfg.census

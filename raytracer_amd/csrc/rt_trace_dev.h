@@ -5,13 +5,26 @@
 #include "rt_ctx.h"
 
 // Traverse the LBVH for one ray.  `stack` points at this lane's column of an LDS array laid out
-// [depth][block_threads] (so that every ds_read/ds_write of a wave touches 64 consecutive dwords
-// -> conflict free), `stride` = threads per block.
+// [lds_depth][block_threads] (so that every ds_read/ds_write of a wave touches 64 consecutive dwords
+// -> conflict free), `stride` = threads per block.  Only the first sv.lds_depth entries of a lane's
+// stack live in LDS (3 KB per wave at depth 12, so the full 32 waves/CU stay resident); deeper
+// entries -- rare -- go to `spill`, this thread's column of an HBM array [..][sv.spill_stride].
 //   ANY = false: closest hit into `best` (prim = RT_MISS / t = +inf on a miss); returns hit?
 //   ANY = true : first accepted hit terminates; returns occluded?
+__device__ __forceinline__ void stack_push(const SceneView& sv, int* stack, int stride, int* spill, int sp, int v)
+{
+	if (sp < sv.lds_depth) stack[sp * stride] = v;
+	else spill[(size_t)(sp - sv.lds_depth) * sv.spill_stride] = v;
+}
+__device__ __forceinline__ int stack_pop(const SceneView& sv, const int* stack, int stride, const int* spill, int sp)
+{
+	if (sp < sv.lds_depth) return stack[sp * stride];
+	return spill[(size_t)(sp - sv.lds_depth) * sv.spill_stride];
+}
+
 template <bool ANY, bool CENSUS>
 __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& best, int* stack, int stride,
-                                          uint32_t& cnt_nodes, uint32_t& cnt_tris)
+                                          int* spill, uint32_t& cnt_nodes, uint32_t& cnt_tris)
 {
 	best.prim = RT_MISS;
 	best.t = sv.tp.t_max;
@@ -38,7 +51,7 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 					bool left_first = tl <= tr;
 					int nearc = left_first ? q3.x : q3.y;
 					int farc = left_first ? q3.y : q3.x;
-					stack[sp * stride] = farc;
+					stack_push(sv, stack, stride, spill, sp, farc);
 					++sp;
 					cur = nearc;
 				} else if (hl) {
@@ -47,7 +60,7 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 					cur = q3.y;
 				} else {
 					if (sp == 0) cur = SENTINEL;
-					else { --sp; cur = stack[sp * stride]; }
+					else { --sp; cur = stack_pop(sv, stack, stride, spill, sp); }
 				}
 			} else {
 				const TriIsect* tp = sv.tris + (~cur);
@@ -60,7 +73,7 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 					if (mt_closest(O, D, v0, e1, e2, __float_as_uint(a.w), sv.tp, best)) found = true;
 				}
 				if (sp == 0) cur = SENTINEL;
-				else { --sp; cur = stack[sp * stride]; }
+				else { --sp; cur = stack_pop(sv, stack, stride, spill, sp); }
 			}
 		}
 	}
@@ -69,9 +82,9 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 }
 
 // Census mode: wave-reduce the per-ray counters, one 64-bit atomic triple per wave.
-__device__ __forceinline__ void census_add(unsigned long long* census, uint32_t nodes, uint32_t tris, bool active)
+__device__ __forceinline__ void census_add(unsigned long long* census, uint32_t nodes, uint32_t tris, uint32_t rays)
 {
-	uint32_t a = nodes, b = tris, c = active ? 1u : 0u;
+	uint32_t a = nodes, b = tris, c = rays;
 	for (int off = 32; off >= 1; off >>= 1) {
 		a += __shfl_xor(a, off);
 		b += __shfl_xor(b, off);
@@ -107,10 +120,11 @@ __device__ __forceinline__ bool brute_trace(const SceneView& sv, f3 O, f3 D, Hit
 }
 
 template <bool ANY>
-__device__ __forceinline__ bool scene_trace(const SceneView& sv, f3 O, f3 D, Hit& best, int* stack, int stride)
+__device__ __forceinline__ bool scene_trace(const SceneView& sv, f3 O, f3 D, Hit& best, int* stack, int stride,
+                                            int* spill)
 {
 	uint32_t a = 0, b = 0;
-	if (sv.use_bvh) return bvh_trace<ANY, false>(sv, O, D, best, stack, stride, a, b);
+	if (sv.use_bvh) return bvh_trace<ANY, false>(sv, O, D, best, stack, stride, spill, a, b);
 	return brute_trace<ANY>(sv, O, D, best);
 }
 
