@@ -249,15 +249,27 @@ __device__ __forceinline__ float unorm16(float c)
 }
 __device__ __forceinline__ float half_round(float f) { return __half2float(__float2half_rn(f)); }
 
+// 8x8 pixel tiles: a wave's 64 lanes cover a square, not a 64x1 strip (2-D coherent rays share
+// BVH nodes).  Item j of a w x h frame -> pixel index, or -1 in the padding of a partial tile.
+__device__ __forceinline__ int tile8_pixel(int j, int w, int h)
+{
+	const int tiles_x = (w + 7) >> 3;
+	const int t = j >> 6, k = j & 63;
+	const int x = ((t % tiles_x) << 3) + (k & 7), y = ((t / tiles_x) << 3) + (k >> 3);
+	return (x < w && y < h) ? y * w + x : -1;
+}
+__host__ __device__ inline int tile8_count(int w, int h) { return ((w + 7) >> 3) * ((h + 7) >> 3) * 64; }
+
 __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, float tanfov, int w, int h,
                                                                  float* __restrict__ nrm_rgba,
                                                                  float* __restrict__ pos_rgb)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
-	const int gtid = blockIdx.x * TRACE_BLOCK + threadIdx.x;
-	const int gsize = gridDim.x * TRACE_BLOCK;
-	int* spill = sv.spill + gtid;
-	for (int i = gtid; i < w * h; i += gsize) {
+	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
+	int* spill = sv.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
+	grid_for_each(tile8_count(w, h), [&](int64_t j) {
+		const int i = tile8_pixel((int)j, w, h);
+		if (i < 0) return;
 		int x = i % w, y = i / w;
 		float aspect = float(w) / h;
 		float dirX = (float)(2 * ((x + 0.5) / w) - 1);
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
 			}
 		} else {
 			Hit best;
-			scene_trace<false>(sv, O, D, best, smem + threadIdx.x, TRACE_BLOCK, spill);
+			scene_trace<false>(sv, O, D, best, stack, TRACE_BLOCK, spill);
 			if (best.prim != RT_MISS) {
 				HitInfo hi;
 				resolve_tri(sv, best, hi, nullptr);
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
 		pos_rgb[3 * (size_t)i + 0] = half_round(P.x);
 		pos_rgb[3 * (size_t)i + 1] = half_round(P.y);
 		pos_rgb[3 * (size_t)i + 2] = half_round(P.z);
-	}
+	});
 }
 
 // ---- Gen-1 shade() wavefront ---------------------------------------------------------------------
@@ -312,30 +324,36 @@ __device__ __forceinline__ bool tile_is_mine(int pixel, int w, int tile, int ran
 	return ((tx + ty) % nranks) == rank;
 }
 
+// Level-0 nodes are stored in 8x8-tile order (node j <-> pixel tile8_pixel(j)); every later level
+// is a compaction of its parent level, so the whole tree of a frame inherits the 2-D locality.
 __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__ pos_rgb,
-                                                      const float* __restrict__ nrm_rgba, int w, int h, int tile,
+                                                      const float* __restrict__ nrm_rgba, int w, int h, int n0, int tile,
                                                       int rank, int nranks, int num_materials,
                                                       NodeGeo* __restrict__ geo, int* __restrict__ active_count)
 {
-	int i = blockIdx.x * CBLOCK + threadIdx.x;
+	int j = blockIdx.x * CBLOCK + threadIdx.x;
 	bool active = false;
-	if (i < w * h) {
-	NodeGeo g;
-	float a = nrm_rgba[4 * (size_t)i + 3];
-	int mat = (a > 0.0f) ? ((int)a - 1) : -1;
-	if (mat >= num_materials) mat = -1;
-	if (!tile_is_mine(i, w, tile, rank, nranks)) mat = -2;  // -2: not this rank's texel, leave the pixel alone
-	f3 P = ld3(pos_rgb + 3 * (size_t)i);
-	f3 N;
-	// decode as getRayTraceData does (c*2-1 in double, not renormalised)
-	N.x = (float)((double)nrm_rgba[4 * (size_t)i + 0] * 2.0 - 1.0);
-	N.y = (float)((double)nrm_rgba[4 * (size_t)i + 1] * 2.0 - 1.0);
-	N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
-	st3(g.V, P); st3(g.N, N);
-	st3(g.I, mat >= 0 ? normalized3(P) : mk3(0, 0, 0));
-	g.parent = i; g.material = mat; g.branch = 0;
-	geo[i] = g;
-	active = mat >= 0;
+	if (j < n0) {
+		const int i = tile8_pixel(j, w, h);
+		NodeGeo g;
+		int mat = -2;  // -2: padding of a partial tile, or not this rank's texel: leave the pixel alone
+		f3 P = mk3(0, 0, 0), N = mk3(0, 0, 0);
+		if (i >= 0) {
+			float a = nrm_rgba[4 * (size_t)i + 3];
+			mat = (a > 0.0f) ? ((int)a - 1) : -1;
+			if (mat >= num_materials) mat = -1;
+			if (!tile_is_mine(i, w, tile, rank, nranks)) mat = -2;
+			P = ld3(pos_rgb + 3 * (size_t)i);
+			// decode as getRayTraceData does (c*2-1 in double, not renormalised)
+			N.x = (float)((double)nrm_rgba[4 * (size_t)i + 0] * 2.0 - 1.0);
+			N.y = (float)((double)nrm_rgba[4 * (size_t)i + 1] * 2.0 - 1.0);
+			N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
+		}
+		st3(g.V, P); st3(g.N, N);
+		st3(g.I, mat >= 0 ? normalized3(P) : mk3(0, 0, 0));
+		g.parent = i; g.material = mat; g.branch = 0;
+		geo[j] = g;
+		active = mat >= 0;
 	}
 	// one counter add per workgroup
 	__shared__ int s_cnt;
@@ -356,15 +374,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const Node
 {
 	if (shadow_t_max > 0.0f) sv.tp.t_max = shadow_t_max;
 	extern __shared__ __attribute__((aligned(16))) int smem[];
-	const int64_t gtid = (int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x;
-	const int64_t gsize = (int64_t)gridDim.x * TRACE_BLOCK;
-	const int64_t total = (int64_t)n * sv.num_lights;
-	int* spill = sv.spill + gtid;
+	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
+	int* spill = sv.spill + ((int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x);
 	uint32_t cn = 0, ct = 0, rays = 0;
-	for (int64_t idx = gtid; idx < total; idx += gsize) {
+	grid_for_each((int64_t)n * sv.num_lights, [&](int64_t idx) {
 		int light = (int)(idx / n), i = (int)(idx % n);
 		const NodeGeo g = geo[i];
-		if (g.material < 0) continue;
+		if (g.material < 0) return;
 		++rays;
 		f3 V = ld3(g.V), N = ld3(g.N);
 		f3 L = ld3(sv.lights[light].position) - V;
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const Node
 		} else if (sv.use_bvh) {
 			Hit best;
 			uint32_t a = 0, b = 0;
-			blocked = bvh_trace<true, CENSUS>(sv, O, L, best, smem + threadIdx.x, TRACE_BLOCK, spill, a, b);
+			blocked = bvh_trace<true, CENSUS>(sv, O, L, best, stack, TRACE_BLOCK, spill, a, b);
 			cn += a; ct += b;
 		} else {
 			Hit best;
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const Node
 		}
 		// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116)
 		if (blocked && 0.0f < norm3(L)) atomicOr(&occl[i], 1u << light);
-	}
+	});
 	if (CENSUS && census) census_add(census, cn, ct, rays);
 }
 
@@ -722,7 +738,7 @@ int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgb
 	SceneView sv = rt_scene_view(ctx);
 	float tanfov = tanf(fov);  // Camera::setFOV (data/camera.cpp:41-44)
 	size_t lds = rt_trace_lds(sv, TRACE_BLOCK);
-	hipLaunchKernelGGL(k_primary_gbuffer, dim3(rt_trace_blocks(ctx, (int64_t)w * h, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, ctx->stream,
+	hipLaunchKernelGGL(k_primary_gbuffer, dim3(rt_trace_blocks(ctx, tile8_count(w, h), TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, ctx->stream,
 	                   sv, tanfov, w, h, d_nrm_rgba, d_pos_rgb);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
@@ -752,9 +768,10 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 	hipStream_t st = ctx->stream;
 	SceneView sv = rt_scene_view(ctx);
 	const int bounces = ctx->cfg.bounces;
-	const int npix = w * h;
 	ctx->last_frame_rays = 0;
-	if (npix <= 0 || bounces <= 0) return RT_HIP_OK;
+	if (w <= 0 || h <= 0 || bounces <= 0) return RT_HIP_OK;
+	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 28) { rt_set_error("frame larger than 2^28 texels"); return RT_HIP_ERR_LIMIT; }
+	const int npix = tile8_count(w, h);  // level-0 nodes: the frame padded to whole 8x8 tiles
 	if (bounces > 8) { rt_set_error("bounces > 8 not supported"); return RT_HIP_ERR_LIMIT; }
 	if (sv.num_lights > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
 	const bool spheres = sv.num_spheres > 0 && sv.num_tris == 0;
@@ -780,7 +797,7 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 
 	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
 	RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 64, st));
-	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(npix, CBLOCK)), dim3(CBLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, tile, rank,
+	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(npix, CBLOCK)), dim3(CBLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, npix, tile, rank,
 	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), qcount + 8);
 	RT_HIP_CHECK(hipGetLastError());
 	int active0 = 0;

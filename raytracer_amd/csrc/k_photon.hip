@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_photon_emit(SceneView sv, int per_lig
 	// emit_photon(): `pass++` hands the OLD value down, so every level runs with pass == 0 (:66)
 	for (int depth = 0; depth < (1 << 20); ++depth) {
 		Hit best;
-		scene_trace<false>(sv, origin, dir, best, smem + threadIdx.x, BLOCK, spill);
+		scene_trace<false>(sv, origin, dir, best, RT_LDS_STACK(smem) + threadIdx.x, BLOCK, spill);
 		if (best.prim == RT_MISS) break;
 		const TriPos tp = sv.tri_pos[best.prim];
 		const TriAttr ta = sv.tri_attr[best.prim];

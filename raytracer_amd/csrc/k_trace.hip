@@ -55,23 +55,21 @@ __global__ __launch_bounds__(BVH_BLOCK) void k_bvh(SceneView sv, const float* __
                                                    uint8_t* __restrict__ occ, uint32_t* __restrict__ nv,
                                                    uint32_t* __restrict__ nt, unsigned long long* census)
 {
-	// Persistent grid: at most the device's resident-thread capacity, each thread strides over the
-	// rays; its overflow-stack column in HBM is its global thread id.
+	// Capped grid (see grid_for_each); a thread's overflow-stack column in HBM is its global thread id.
 	extern __shared__ __attribute__((aligned(16))) int smem[];
-	const int gtid = blockIdx.x * BVH_BLOCK + threadIdx.x;
-	const int gsize = gridDim.x * BVH_BLOCK;
-	int* spill = sv.spill + gtid;
+	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
+	int* spill = sv.spill + (blockIdx.x * BVH_BLOCK + threadIdx.x);
 	uint32_t cn = 0, ct = 0, rays = 0;
-	for (int i = gtid; i < n; i += gsize) {
+	grid_for_each(n, [&](int64_t i) {
 		f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
 		Hit best;
 		uint32_t a = 0, b = 0;
-		bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, smem + threadIdx.x, BVH_BLOCK, spill, a, b);
+		bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, stack, BVH_BLOCK, spill, a, b);
 		if (CENSUS && nv) { nv[i] = a; nt[i] = b; }
 		cn += a; ct += b; ++rays;
 		if (ANY) { if (occ) occ[i] = any ? 1 : 0; }
 		else if (hits) hits[i] = best;
-	}
+	});
 	if (CENSUS && census) census_add(census, cn, ct, rays);
 }
 

@@ -79,16 +79,14 @@ size_t rt_debug_extra_lds()
 int rt_lds_depth()
 {
 	static int v = -1;
-	if (v < 0) { const char* e = getenv("RT_HIP_LDS_DEPTH"); v = e ? atoi(e) : 12; if (v < 1) v = 1; }
+	if (v < 0) { const char* e = getenv("RT_HIP_LDS_DEPTH"); v = e ? atoi(e) : 16; if (v < 1) v = 1; }
 	return v;
 }
 
 int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block)
 {
 	int64_t need = (work_items + block - 1) / block;
-	static int mult = -1;  // RT_HIP_GRID_MULT: experiments only (values > 1 are unsafe unless nothing spills)
-	if (mult < 0) { const char* e = getenv("RT_HIP_GRID_MULT"); mult = e ? atoi(e) : 1; if (mult < 1) mult = 1; }
-	int64_t cap = std::max<int64_t>(1, (int64_t)ctx->max_trace_threads / block * mult);
+	int64_t cap = std::max<int64_t>(1, (int64_t)ctx->max_trace_threads / block);
 	return (int)std::max<int64_t>(1, std::min(need, cap));
 }
 
@@ -254,8 +252,8 @@ int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out)
 	{
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
-			ctx->max_trace_threads = prop.multiProcessorCount * prop.maxThreadsPerMultiProcessor;
-		if (ctx->max_trace_threads <= 0) ctx->max_trace_threads = 256 * 2048;
+			ctx->max_trace_threads = RT_TRACE_OVERSUB * prop.multiProcessorCount * prop.maxThreadsPerMultiProcessor;
+		if (ctx->max_trace_threads <= 0) ctx->max_trace_threads = RT_TRACE_OVERSUB * 256 * 2048;
 	}
 	hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);

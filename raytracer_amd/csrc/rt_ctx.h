@@ -82,7 +82,7 @@ struct rt_hip_ctx {
 	std::vector<int> trace_event_class;                           // 0 closest, 1 any
 	size_t trace_events_used = 0;
 	DevBuf d_census, d_spill;
-	int max_trace_threads = 0;                                    // resident-thread capacity of the device                                              // 6 x u64 (census mode)
+	int max_trace_threads = 0;  // grid cap of the trace kernels = RT_TRACE_OVERSUB x resident-thread capacity
 
 	std::vector<HostMesh> meshes;
 	std::vector<HostSphere> spheres;
@@ -120,9 +120,10 @@ struct rt_hip_ctx {
 
 SceneView rt_scene_view(const rt_hip_ctx* ctx);
 size_t rt_debug_extra_lds();
-int rt_lds_depth();           // RT_HIP_LDS_DEPTH, default 12
-// Persistent launch shape of the trace kernels: blocks of `block` threads, at most the device's
-// resident-thread capacity in total (the spill stack is sized for exactly that many threads).
+int rt_lds_depth();           // RT_HIP_LDS_DEPTH, default 16
+constexpr int RT_TRACE_OVERSUB = 4;
+// Launch shape of the trace kernels: blocks of `block` threads, at most ctx->max_trace_threads in
+// total (the spill stack has exactly that many columns).
 int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block);
 size_t rt_trace_lds(const SceneView& sv, int block);  // RT_HIP_EXTRA_LDS (bytes): occupancy experiments only
 int rt_begin_trace_timing(rt_hip_ctx* ctx);

@@ -169,9 +169,13 @@ __device__ __forceinline__ bool mt_occlude_ref(f3 O, f3 D, f3 v0, f3 e1, f3 e2, 
 // a slab test on boxes that were padded at build time.  (b - o) * inv carries <= 2 ulp of
 // relative error, so the interval is widened by 4 ulp on each side and the test never rejects a
 // box whose triangle the exact M-T test would accept.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct RayPre {
-	f3 o;
-	f3 inv;  // 1/d with |d| < 1e-20 replaced by +-1e-20 before inversion (no inf, no 0*inf NaN)
+	// origin and reciprocal direction, pre-paired the way the node's 12 floats pair up
+	// ((x,y) (z,x) (y,z)), so that the 24 sub/mul of a node visit issue as 12 packed-FP32 ops.
+	v2f o_xy, o_zx, o_yz;
+	v2f i_xy, i_zx, i_yz;  // 1/d with |d| < 1e-20 replaced by +-1e-20 before inversion (no inf, no 0*inf NaN)
 };
 
 __device__ __forceinline__ float safe_rcp(float d)
@@ -180,27 +184,37 @@ __device__ __forceinline__ float safe_rcp(float d)
 	return 1.0f / s;
 }
 
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+
 __device__ __forceinline__ RayPre ray_pre(f3 o, f3 d)
 {
 	RayPre r;
-	r.o = o;
-	r.inv = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+	float ix = safe_rcp(d.x), iy = safe_rcp(d.y), iz = safe_rcp(d.z);
+	r.o_xy = mk2(o.x, o.y); r.o_zx = mk2(o.z, o.x); r.o_yz = mk2(o.y, o.z);
+	r.i_xy = mk2(ix, iy); r.i_zx = mk2(iz, ix); r.i_yz = mk2(iy, iz);
 	return r;
 }
 
-// Hit iff the widened slab interval intersects [0, tlimit]; entry distance in `tnear`.
-__device__ __forceinline__ bool slab(const RayPre& r, float mnx, float mny, float mnz, float mxx, float mxy,
-                                     float mxz, float tlimit, float& tnear)
+// Both child boxes of a node against one ray.  Hit iff the widened slab interval intersects
+// [0, tlimit]; entry distances in tl / tr.  q0..q2 as laid out in BvhNode.
+__device__ __forceinline__ void slab2(const RayPre& r, float4 q0, float4 q1, float4 q2, float tlimit, bool& hl,
+                                      bool& hr, float& tl, float& tr)
 {
-	float x0 = (mnx - r.o.x) * r.inv.x, x1 = (mxx - r.o.x) * r.inv.x;
-	float y0 = (mny - r.o.y) * r.inv.y, y1 = (mxy - r.o.y) * r.inv.y;
-	float z0 = (mnz - r.o.z) * r.inv.z, z1 = (mxz - r.o.z) * r.inv.z;
-	float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-	float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-	tn *= 0.9999995f;
-	tf *= 1.0000005f;
-	tnear = tn;
-	return tn <= fminf(tf, tlimit);
+	v2f a = (mk2(q0.x, q0.y) - r.o_xy) * r.i_xy;  // l: x0 y0
+	v2f b = (mk2(q0.z, q0.w) - r.o_zx) * r.i_zx;  // l: z0 x1
+	v2f c = (mk2(q1.x, q1.y) - r.o_yz) * r.i_yz;  // l: y1 z1
+	v2f d = (mk2(q1.z, q1.w) - r.o_xy) * r.i_xy;  // r: x0 y0
+	v2f e = (mk2(q2.x, q2.y) - r.o_zx) * r.i_zx;  // r: z0 x1
+	v2f f = (mk2(q2.z, q2.w) - r.o_yz) * r.i_yz;  // r: y1 z1
+	float tnl = fmaxf(fmaxf(fminf(a.x, b.y), fminf(a.y, c.x)), fmaxf(fminf(b.x, c.y), 0.0f));
+	float tfl = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fmaxf(b.x, c.y));
+	float tnr = fmaxf(fmaxf(fminf(d.x, e.y), fminf(d.y, f.x)), fmaxf(fminf(e.x, f.y), 0.0f));
+	float tfr = fminf(fminf(fmaxf(d.x, e.y), fmaxf(d.y, f.x)), fmaxf(e.x, f.y));
+	v2f tn = mk2(tnl, tnr) * 0.9999995f;
+	v2f tf = mk2(tfl, tfr) * 1.0000005f;
+	tl = tn.x; tr = tn.y;
+	hl = tn.x <= fminf(tf.x, tlimit);
+	hr = tn.y <= fminf(tf.y, tlimit);
 }
 
 // ---- wave helpers ---------------------------------------------------------------------------
