@@ -228,6 +228,19 @@ int rt_hip_render_tiles_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, con
 /* Secondary rays issued by the last frame call (shadow + reflection + refraction). */
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx);
 
+/* ---- live shading of the hit records (the raypass) ------------------------------------------ */
+/* rasterizer/shaders/mesh_fs.cpp:26-49 evaluated at each hit record the way Rasterizer::drawRayData
+ * (ras_rasterizer.cpp:619-669) draws it: one point per record with its group's material, the
+ * reflection term 0 (the raypass target is itself the reflection source), at most LIGHT_COUNT = 8
+ * lights (mesh_fs.cpp:5), light and material colours / 255 (ras_rasterizer.cpp:184-188,232).
+ * results / offsets are what rt_hip_process_gbuffer returned (groups = (material, cumulative end)).
+ * rgb_out: n_results x 3 floats; rgb8_out (may be NULL): the RGB8 target's UNORM8 value.
+ * `offsets` is a host pointer in both variants (it is tiny). */
+int rt_hip_shade_results(rt_hip_ctx* ctx, const rt_ray* results, const rt_result_offset* offsets, int n_results,
+                         int n_groups, float* rgb_out, uint8_t* rgb8_out);
+int rt_hip_shade_results_device(rt_hip_ctx* ctx, const rt_ray* d_results, const rt_result_offset* offsets,
+                                int n_results, int n_groups, float* d_rgb_out, uint8_t* d_rgb8_out);
+
 /* ---- photon map (raytracer/rt_photon_map.h:13-16) ------------------------------------------ */
 /* PhotonMap::generate (rt_photon_map.cpp:86-124) for photon indices [first, first+count) of the
  * global sequence lights x photons_per_light, with the counter RNG keyed by (seed, index) so the

@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "rt_hip_trace_any_device", "rt_hip_gbuffer_select_device", "rt_hip_render_gbuffer_device", "rt_hip_render_frame",
     "rt_hip_render_frame_device", "rt_hip_render_tiles_device", "rt_hip_last_frame_rays", "rt_hip_photon_emit_device",
     "rt_hip_photon_set_device", "rt_hip_photon_set", "rt_hip_radiance_estimate_device", "rt_hip_radiance_estimate",
+    "rt_hip_shade_results", "rt_hip_shade_results_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device",
 ]
@@ -132,6 +133,8 @@ def load_library() -> C.CDLL:
     L.rt_hip_photon_set.argtypes = [P, c_float_p, C.c_int64]
     L.rt_hip_radiance_estimate_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_float, P]
     L.rt_hip_radiance_estimate.argtypes = [P, c_float_p, c_float_p, C.c_int, C.c_int, C.c_float, c_float_p]
+    L.rt_hip_shade_results.argtypes = [P, P, P, C.c_int, C.c_int, c_float_p, P]
+    L.rt_hip_shade_results_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
     L.rt_hip_get_stats.argtypes = [P, C.POINTER(Stats)]
     L.rt_hip_reset_stats.argtypes = [P]
     L.rt_hip_sync.argtypes = [P]
@@ -343,6 +346,23 @@ class RtHip:
 
     def radiance_estimate_device(self, d_pos, d_nrm, npts, count, radius, d_out):
         self._ck(self.lib.rt_hip_radiance_estimate_device(self.h, _dptr(d_pos), _dptr(d_nrm), npts, count, radius, _dptr(d_out)))
+
+    # ---- live shading of hit records (mesh_fs.cpp:26-49 as drawRayData applies it) ----------
+    def shade_results(self, records, offsets, want_rgb8=True):
+        records = np.ascontiguousarray(records, RAY_DTYPE)
+        offsets = np.ascontiguousarray(offsets, OFFSET_DTYPE)
+        n = records.shape[0]
+        rgb = np.zeros((n, 3), np.float32)
+        rgb8 = np.zeros((n, 3), np.uint8) if want_rgb8 else None
+        self._ck(self.lib.rt_hip_shade_results(self.h, records.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p),
+                                               n, offsets.shape[0], _p(rgb),
+                                               rgb8.ctypes.data_as(C.c_void_p) if want_rgb8 else None))
+        return (rgb, rgb8) if want_rgb8 else rgb
+
+    def shade_results_device(self, d_records, offsets, n, d_rgb, d_rgb8=None):
+        offsets = np.ascontiguousarray(offsets, OFFSET_DTYPE)
+        self._ck(self.lib.rt_hip_shade_results_device(self.h, _dptr(d_records), offsets.ctypes.data_as(C.c_void_p), n,
+                                                      offsets.shape[0], _dptr(d_rgb), _dptr(d_rgb8) if d_rgb8 is not None else None))
 
     # ---- introspection --------------------------------------------------------------------
     def stats(self):

@@ -586,9 +586,65 @@ __global__ __launch_bounds__(BLOCK) void k_node_points(const NodeGeo* __restrict
 	for (int k = 0; k < 3; ++k) { pos[3 * (size_t)i + k] = geo[i].V[k]; nrm[3 * (size_t)i + k] = geo[i].N[k]; }
 }
 
+// ---- live shading of hit records (a20) -----------------------------------------------------------
+// mesh_fs.cpp:26-49 at one hit record, as drawRayData draws it into the raypass target: the
+// record's group gives the material; reflection term = 0.  One lane per record.
+__global__ __launch_bounds__(BLOCK) void k_shade_results(SceneView sv, const rt_ray* __restrict__ rec, int n,
+                                                         const rt_result_offset* __restrict__ groups, int ngroups,
+                                                         float* __restrict__ rgb, uint8_t* __restrict__ rgb8)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	// group g holds records [end(g-1), end(g)): first g with end(g) > i
+	int lo = 0, hi = ngroups - 1;
+	while (lo < hi) {
+		int mid = (lo + hi) >> 1;
+		if (groups[mid].end > i) hi = mid; else lo = mid + 1;
+	}
+	const MaterialRec m = sv.materials[groups[lo].material];
+	f3 albedo = div3(ld3(m.diffuse), 255.0f), scol = div3(ld3(m.specular), 255.0f);
+	f3 pos = ld3(rec[i].position);
+	f3 N = normalized3(ld3(rec[i].normal));
+	f3 E = normalized3(neg3(pos));
+	f3 direct = mk3(0, 0, 0);
+	const int nl = sv.num_lights < 8 ? sv.num_lights : 8;  // LIGHT_COUNT (mesh_fs.cpp:5)
+	for (int l = 0; l < nl; ++l) {
+		f3 L = ld3(sv.lights[l].position) - pos;
+		f3 energy = ld3(sv.lights[l].color) * (1.0f / 255);
+		float len = norm3(L);
+		energy = energy * (50.0f / (50.0f + len * len));
+		L = normalized3(L);
+		f3 H = normalized3(L + E);
+		float lambert = fminf(fmaxf(dot3(N, L), 0.0f), 1.0f);
+		float phong = powf(fminf(fmaxf(dot3(N, H), 0.0f), 1.0f), m.shininess);
+		direct.x = energy.x * albedo.x * lambert + energy.x * scol.x * phong + direct.x;
+		direct.y = energy.y * albedo.y * lambert + energy.y * scol.y * phong + direct.y;
+		direct.z = energy.z * albedo.z * lambert + energy.z * scol.z * phong + direct.z;
+	}
+	const float refl = m.reflectivity;
+	f3 c = mk3(refl * 0.0f + (1.0f - refl) * direct.x, refl * 0.0f + (1.0f - refl) * direct.y,
+	           refl * 0.0f + (1.0f - refl) * direct.z);
+	st3(rgb + 3 * (size_t)i, c);
+	if (rgb8) {  // GL UNORM8 conversion of the RGB8 raypass target
+		rgb8[3 * (size_t)i + 0] = (uint8_t)rintf(fminf(fmaxf(c.x, 0.0f), 1.0f) * 255.0f);
+		rgb8[3 * (size_t)i + 1] = (uint8_t)rintf(fminf(fmaxf(c.y, 0.0f), 1.0f) * 255.0f);
+		rgb8[3 * (size_t)i + 2] = (uint8_t)rintf(fminf(fmaxf(c.z, 0.0f), 1.0f) * 255.0f);
+	}
+}
+
 }  // namespace
 
 // ================================================================================================
+int rt_launch_shade_results(rt_hip_ctx* ctx, const rt_ray* d_rec, int n, const rt_result_offset* d_groups, int ngroups,
+                            float* d_rgb, uint8_t* d_rgb8)
+{
+	if (n <= 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_shade_results, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, rt_scene_view(ctx), d_rec, n,
+	                   d_groups, ngroups, d_rgb, d_rgb8);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
 int rt_launch_split_rays(rt_hip_ctx* ctx, const rt_ray* d_rays, int n, float* d_org, float* d_dir)
 {
 	if (n <= 0) return RT_HIP_OK;

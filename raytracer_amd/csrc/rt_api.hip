@@ -708,6 +708,58 @@ int rt_hip_radiance_estimate(rt_hip_ctx* ctx, const float* pos, const float* nrm
 	return RT_HIP_OK;
 }
 
+// ---- live shading of hit records -----------------------------------------------------------------
+static int check_groups(const rt_result_offset* offsets, int n_results, int n_groups, int num_materials)
+{
+	int prev = 0;
+	for (int g = 0; g < n_groups; ++g) {
+		if (offsets[g].end < prev || (int)offsets[g].material < 0 || (int)offsets[g].material >= num_materials) {
+			rt_set_error("group %d: bad material id or non-monotonic end offset", g);
+			return RT_HIP_ERR_ARG;
+		}
+		prev = offsets[g].end;
+	}
+	if (prev != n_results) { rt_set_error("groups cover %d records, n_results = %d", prev, n_results); return RT_HIP_ERR_ARG; }
+	return RT_HIP_OK;
+}
+
+int rt_hip_shade_results_device(rt_hip_ctx* ctx, const rt_ray* d_results, const rt_result_offset* offsets, int n_results,
+                                int n_groups, float* d_rgb_out, uint8_t* d_rgb8_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (n_results < 0 || n_groups < 0 || (n_results > 0 && (!d_results || !offsets || !d_rgb_out || n_groups == 0))) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	if (n_results == 0) return RT_HIP_OK;
+	RT_CHECK(check_groups(offsets, n_results, n_groups, (int)ctx->materials.size()));
+	RT_CHECK(ctx->d_offsets.reserve((size_t)n_groups * sizeof(rt_result_offset)));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_offsets.p, offsets, (size_t)n_groups * sizeof(rt_result_offset), hipMemcpyHostToDevice,
+	                            ctx->stream));
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // `offsets` is pageable host memory owned by the caller
+	return rt_launch_shade_results(ctx, d_results, n_results, ctx->d_offsets.as<rt_result_offset>(), n_groups, d_rgb_out,
+	                               d_rgb8_out);
+}
+
+int rt_hip_shade_results(rt_hip_ctx* ctx, const rt_ray* results, const rt_result_offset* offsets, int n_results,
+                         int n_groups, float* rgb_out, uint8_t* rgb8_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (n_results < 0 || (n_results > 0 && (!results || !offsets || !rgb_out))) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	if (n_results == 0) return RT_HIP_OK;
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_records.reserve((size_t)n_results * sizeof(rt_ray)));
+	RT_CHECK(ctx->d_accum.reserve((size_t)n_results * 12));
+	RT_CHECK(ctx->d_occ.reserve((size_t)n_results * 3));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_records.p, results, (size_t)n_results * sizeof(rt_ray), hipMemcpyHostToDevice, st));
+	RT_CHECK(rt_hip_shade_results_device(ctx, ctx->d_records.as<rt_ray>(), offsets, n_results, n_groups,
+	                                     ctx->d_accum.as<float>(), rgb8_out ? ctx->d_occ.as<uint8_t>() : nullptr));
+	RT_HIP_CHECK(hipMemcpyAsync(rgb_out, ctx->d_accum.p, (size_t)n_results * 12, hipMemcpyDeviceToHost, st));
+	if (rgb8_out) RT_HIP_CHECK(hipMemcpyAsync(rgb8_out, ctx->d_occ.p, (size_t)n_results * 3, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	return RT_HIP_OK;
+}
+
 // ---- introspection -------------------------------------------------------------------------------
 int rt_hip_get_stats(rt_hip_ctx* ctx, rt_hip_stats* out)
 {

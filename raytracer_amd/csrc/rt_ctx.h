@@ -158,6 +158,8 @@ int rt_group_by_material(rt_hip_ctx* ctx, const float* d_org, const float* d_dir
                          rt_ray* d_records, rt_result_offset* d_offsets, int* out_results, int* out_groups);
 int rt_gbuffer_select(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n, int interlace,
                       int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* out_count);
+int rt_launch_shade_results(rt_hip_ctx* ctx, const rt_ray* d_rec, int n, const rt_result_offset* d_groups, int ngroups,
+                            float* d_rgb, uint8_t* d_rgb8);
 int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb);
 int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
                     int rank, int nranks, uint8_t* d_rgba);

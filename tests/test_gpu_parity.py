@@ -364,3 +364,35 @@ def test_spheres_frame(rt, oracle_cls):
     assert diff.max() <= 1
     assert (mid >= 0).sum() > 500
     g.close()
+
+
+# ---- a20: live shading of the hit records (mesh_fs.cpp:26-49 as drawRayData applies it) ---------
+@pytest.mark.parametrize("scene_fn", [scenes.cornell, lambda: scenes.atrium(2048)], ids=["cornell", "atrium2k"])
+def test_shade_results(rt, oracle_cls, scene_fn):
+    """processRays -> shade_results, i.e. the reference's raypass (scene.cpp:51-52).  The oracle's
+    restatement of the GLSL is 'parity unpinned' (no GL here); tolerance: powf differs between
+    libm and the device library, 2e-5 relative; the UNORM8 value may differ by one code."""
+    sc = scene_fn()
+    orc = oracle_cls(sc)
+    g = rt.RtHip(sc, accel=2)
+    pos, nrm, _ = _gbuf_samples(orc, 128, 96)
+    out = g.process_rays(pos, nrm)
+    rec = out["records"]
+    off = np.zeros(len(out["offset_end"]), rt.OFFSET_DTYPE)
+    off["material"], off["end"] = out["offset_material"], out["offset_end"]
+    assert rec.shape[0] > 500 and len(off) >= 2
+    mid = np.repeat(off["material"].astype(np.int32), np.diff(np.concatenate([[0], off["end"]])))
+    want = orc.shade_records(rec, mid)
+    rgb, rgb8 = g.shade_results(rec, off)
+    assert np.isfinite(rgb).all() and rgb.max() > 0.05
+    np.testing.assert_allclose(rgb, want, rtol=2e-5, atol=1e-6)
+    want8 = np.rint(np.clip(want, 0, 1) * 255).astype(np.int32)
+    assert np.abs(rgb8.astype(np.int32) - want8).max() <= 1
+    assert (rgb8.astype(np.int32) == want8).mean() > 0.999
+    # empty input and malformed groups
+    e_rgb, e8 = g.shade_results(rec[:0], off[:0])
+    assert e_rgb.shape == (0, 3)
+    bad = off.copy(); bad["end"][-1] += 1
+    with pytest.raises(rt.RtHipError):
+        g.shade_results(rec, bad)
+    g.close()
