@@ -47,6 +47,10 @@ def parse_args():
                     choices=["atrium-262k-1080p", "atrium-1m-1080p", "atrium-1m-4k", "cornell-1080p", "atrium-8k-small"])
     ap.add_argument("--shadow-mode", default="corrected", choices=["corrected", "literal"],
                     help="corrected: a hit shadows only before the light (shadow_t_max=1); literal: the reference's any-hit")
+    ap.add_argument("--photons", type=int, default=0,
+                    help="C5: photons per light (0 = off).  The sharded photon pass (emit -> RCCL all-gather -> grid) runs once, "
+                         "untimed by `value` and reported as config.photon_pass_ms; frames then shade with radiance_estimate "
+                         "instead of shadow rays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="G-buffer texels fed to the CPU baseline (0 = auto)")
     return ap.parse_args()
@@ -89,8 +93,18 @@ def main():
     scene = scenes.cornell() if wl["tris"] == 0 else scenes.atrium(wl["tris"])
     shadow_t_max = 1.0 if args.shadow_mode == "corrected" else 0.0
     g = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_LBVH, device=local_rank, profile=1, bounces=2, do_shadows=1,
-                 shadow_t_max=shadow_t_max)
+                 shadow_t_max=shadow_t_max, use_photon_map=1 if args.photons > 0 else 0, photon_estimate=100,
+                 photon_radius=1.0, seed=42)
     build_stats = g.stats()
+    photon_info = None
+    if args.photons > 0:
+        from raytracer_amd.photons import build_photon_map
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        nph = build_photon_map(g, args.photons, len(scene.lights), dev)
+        g.sync()
+        photon_info = {"photons_per_light": args.photons, "photons_stored": nph,
+                       "photon_pass_ms": round((time.perf_counter() - t0) * 1e3, 3)}
 
     # ---- inputs resident in HBM: one G-buffer per frame of the step -------------------------
     nframes = world
@@ -190,12 +204,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "scene": scene.name, "triangles": scene.num_tris, "width": W, "height": H,
+            "config": {"workload": args.workload + ("+photons" if args.photons > 0 else ""), "scene": scene.name, "triangles": scene.num_tris, "width": W, "height": H,
                        "frames_per_step": nframes, "tile": 64, "bounces": 2, "lights": len(scene.lights),
                        "shadows": args.shadow_mode, "accel": "lbvh", "parallelism": "tiles x%d" % world,
                        "rays_per_frame": round(total_rays / args.steps / nframes, 1),
                        "ms_per_frame": round(elapsed / args.steps * 1e3, 3),
-                       "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"]},
+                       "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"],
+                       **({"photon_map": photon_info} if photon_info else {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

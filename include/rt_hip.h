@@ -245,7 +245,8 @@ int rt_hip_shade_results_device(rt_hip_ctx* ctx, const rt_ray* d_results, const 
 /* PhotonMap::generate (rt_photon_map.cpp:86-124) for photon indices [first, first+count) of the
  * global sequence lights x photons_per_light, with the counter RNG keyed by (seed, index) so the
  * result does not depend on how indices are sharded.  Stored photons (9 floats: position,
- * energy, direction) are appended to d_photons_out in index order; *out_stored = how many. */
+ * energy, direction) are appended to d_photons_out in index order; *out_stored = how many.
+ * A photon is stored at most once, so capacity (in photons) must be >= count. */
 int rt_hip_photon_emit_device(rt_hip_ctx* ctx, int photons_per_light, int64_t first, int64_t count,
                               float* d_photons_out, int64_t capacity, int64_t* out_stored);
 /* Install the (all-gathered) photon set and build the hashed grid (cell = radius). */

@@ -90,6 +90,7 @@ class Oracle:
                                         c_u8_p, c_float_p, C.POINTER(C.c_int64)]
         L.orc_shade_records.argtypes = [C.c_void_p, C.c_int, C.c_void_p, c_int_p, c_float_p]
         L.orc_photon_generate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
+        L.orc_photon_generate_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int64]
         L.orc_photon_count.argtypes = [C.c_void_p]
         L.orc_photon_get.argtypes = [C.c_void_p, c_float_p]
         L.orc_photon_set.argtypes = [C.c_void_p, C.c_int, c_float_p]
@@ -268,6 +269,13 @@ class Oracle:
     def photon_generate(self, count, geometry=0, rng=0, seed=0):
         n = self.lib.orc_photon_generate(self.h, count, geometry, rng, C.c_uint64(seed))
         out = np.zeros((n, 9), np.float32)
+        self.lib.orc_photon_get(self.h, _p(out))
+        return out
+
+    def photon_generate_range(self, count, first, n, geometry=0, seed=0):
+        """Counter-RNG photons of the global indices [first, first+n) only (one rank's shard)."""
+        k = self.lib.orc_photon_generate_range(self.h, count, geometry, C.c_uint64(seed), C.c_int64(first), C.c_int64(n))
+        out = np.zeros((k, 9), np.float32)
         self.lib.orc_photon_get(self.h, _p(out))
         return out
 

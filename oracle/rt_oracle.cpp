@@ -1092,6 +1092,37 @@ int orc_photon_generate(orc_scene* s, int count, int geometry, int rng_mode, uin
 	return (int)s->photons.size();
 }
 
+// The counter-RNG sequence restricted to global photon indices [first, first+n) (index =
+// light * count + j): what one rank of the sharded GPU pass emits.  Same loop body as above.
+int orc_photon_generate_range(orc_scene* s, int count, int geometry, uint64_t seed, int64_t first, int64_t n)
+{
+	if (geometry == 0) ensure_array(s); else ensure_spheres(s);
+	s->photons.clear();
+	const float max_dist = 12;
+	const float rmax_2 = RAND_MAX / 2.0;
+	Rng rng;
+	rng.mode = 1;
+	rng.seed_lo = (uint32_t)seed; rng.seed_hi = (uint32_t)(seed >> 32);
+	const int64_t total = (int64_t)s->lights.size() * count;
+	for (int64_t g = std::max<int64_t>(first, 0); g < std::min(first + n, total); ++g) {
+		const Light& light = s->lights[(size_t)(g / count)];
+		V3 energy = divs(mul(light.color, 5.0f), (float)count);
+		rng.index = (uint32_t)g; rng.counter = 0;
+		V3 dir;
+		do {
+			dir.x = rng.next() / rmax_2 - 1;
+			dir.y = rng.next() / rmax_2 - 1;
+			dir.z = -rng.next() / (float)RAND_MAX;
+		} while (dot(dir, dir) > 1);
+		orc_ray ray;
+		memset(&ray, 0, sizeof(ray));
+		st3(ray.origin, light.position);
+		st3(ray.direction, dir);
+		emit_photon(s, geometry, rng, &ray, energy, max_dist, 1 << 20);
+	}
+	return (int)s->photons.size();
+}
+
 int orc_photon_count(orc_scene* s) { return (int)s->photons.size(); }
 
 void orc_photon_get(orc_scene* s, float* out9)

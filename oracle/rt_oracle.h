@@ -96,6 +96,7 @@ void orc_shade_records(orc_scene* s, int n, const orc_ray* records, const int* m
 /* a22-a25: photon map.  rng: 0 = libc srand(seed)/rand() (the reference's stream),
  * 1 = counter RNG keyed by (seed, photon index) used by the GPU pass.  accel as geometry above. */
 int orc_photon_generate(orc_scene* s, int count, int geometry, int rng, uint64_t seed);
+int orc_photon_generate_range(orc_scene* s, int count, int geometry, uint64_t seed, int64_t first, int64_t n);
 int orc_photon_count(orc_scene* s);
 void orc_photon_get(orc_scene* s, float* out9);
 void orc_photon_set(orc_scene* s, int n, const float* in9);

@@ -303,7 +303,8 @@ int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count,
 	int64_t total = (int64_t)per_light * sv.num_lights;
 	if (first + count > total) { rt_set_error("photon range [%lld,%lld) exceeds lights x per_light = %lld", (long long)first, (long long)(first + count), (long long)total); return RT_HIP_ERR_ARG; }
 	if (count > 0x7FFFFFF0ll) { rt_set_error("more than 2^31 photons per call"); return RT_HIP_ERR_LIMIT; }
-	(void)capacity;
+	// a photon is stored at most once (emit_photon returns after the store, rt_photon_map.cpp:44-52)
+	if (capacity < count) { rt_set_error("photon output capacity %lld < count %lld", (long long)capacity, (long long)count); return RT_HIP_ERR_ARG; }
 	hipStream_t st = ctx->stream;
 	RT_CHECK(ctx->d_photon_tmp.reserve((size_t)count * sizeof(PhotonRec)));
 	RT_CHECK(ctx->d_keys.reserve((size_t)count * 4));

@@ -117,3 +117,31 @@ def test_photon_mapped_frame(oracle_cls):
     assert psnr >= 45.0, psnr
     assert np.abs(got.astype(np.int32) - exp.astype(np.int32)).max() <= 1
     g.close()
+
+
+def test_c5_pipeline_single_rank(oracle_cls):
+    """C5's sequence on one GPU: emit shard -> (all-gather, a no-op at world 1) -> photon_set ->
+    photon-mapped frame, through raytracer_amd.photons.build_photon_map.  The photon set must be the
+    oracle's counter-RNG set bit for bit, the frame within the photon-image bar."""
+    import raytracer_amd as rt
+    from raytracer_amd.photons import build_photon_map
+    sc = scenes.atrium(2048)
+    orc = oracle_cls(sc)
+    per_light = 4000
+    g = rt.RtHip(sc, semantics="array", bounces=1, use_photon_map=1, photon_estimate=50, photon_radius=2.0, seed=42)
+    n = build_photon_map(g, per_light, len(sc.lights), "cuda")
+    ph = orc.photon_generate(per_light, geometry=0, rng=1, seed=42)
+    assert n == ph.shape[0] > 1000
+    w, h = 64, 48
+    nr, po = orc.software_gbuffer(w, h)
+    mid = nr[:, 3].astype(np.int32) - 1
+    nrm = (nr[:, :3].astype(np.float64) * 2.0 - 1.0).astype(np.float32)
+    # radiance at the G-buffer points from the GPU-built map == the oracle's from its own photons
+    orc.photon_set(ph)
+    cov = mid >= 0
+    a = orc.radiance_estimate(po[cov], nrm[cov], 50, 2.0)
+    b = g.radiance_estimate(po[cov], nrm[cov], 50, 2.0)
+    ok = np.isfinite(a).all(1)
+    np.testing.assert_array_equal(np.isfinite(b).all(1), ok)
+    np.testing.assert_allclose(b[ok], a[ok], rtol=1e-5, atol=1e-9)
+    g.close()

@@ -78,3 +78,48 @@ def test_two_rank_frame_equals_single_rank(tmp_path):
     got = np.load(os.path.join(str(tmp_path), "frame.npy"))
     np.testing.assert_array_equal(got, full)
     assert int(np.load(os.path.join(str(tmp_path), "rays.npy"))[0]) == rays
+
+
+# ---- collective #1: the photon all-gather ---------------------------------------------------------
+PER_LIGHT = 600
+
+
+def _photon_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pyoracle import Oracle
+    from raytracer_amd.photons import gather_photons
+    sc = scenes.cornell()
+    orc = Oracle(sc)
+    first, count = photon_shard(PER_LIGHT * len(sc.lights), rank, world)
+    local = orc.photon_generate_range(PER_LIGHT, first, count, seed=42)   # stands in for the GPU emitter
+    full = gather_photons(torch.from_numpy(local.copy()))
+    empty = gather_photons(torch.zeros((0, 9), dtype=torch.float32))           # every shard empty
+    dist.barrier()
+    np.save(os.path.join(out_dir, "photons_%d.npy" % rank), full.numpy())
+    np.save(os.path.join(out_dir, "empty_%d.npy" % rank), empty.numpy())
+    dist.destroy_process_group()
+
+
+def test_photon_range_matches_full_sequence():
+    from oracle.pyoracle import Oracle
+    sc = scenes.cornell()
+    orc = Oracle(sc)
+    whole = orc.photon_generate(PER_LIGHT, rng=1, seed=42)
+    total = PER_LIGHT * len(sc.lights)
+    assert np.array_equal(orc.photon_generate_range(PER_LIGHT, 0, total, seed=42), whole)
+    parts = [orc.photon_generate_range(PER_LIGHT, *photon_shard(total, r, 3), seed=42) for r in range(3)]
+    assert np.array_equal(np.concatenate(parts, 0), whole)
+
+
+def test_two_rank_photon_gather_equals_single_rank(tmp_path):
+    from oracle.pyoracle import Oracle
+    sc = scenes.cornell()
+    whole = Oracle(sc).photon_generate(PER_LIGHT, rng=1, seed=42)
+    assert whole.shape[0] > 100
+    mp.spawn(_photon_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), "photons_%d.npy" % r))
+        assert got.tobytes() == whole.tobytes()          # every rank holds the single-rank array, bit for bit
+        assert np.load(os.path.join(str(tmp_path), "empty_%d.npy" % r)).shape == (0, 9)
