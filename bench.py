@@ -47,6 +47,7 @@ def parse_args():
                     choices=["atrium-262k-1080p", "atrium-1m-1080p", "atrium-1m-4k", "cornell-1080p", "atrium-8k-small"])
     ap.add_argument("--shadow-mode", default="corrected", choices=["corrected", "literal"],
                     help="corrected: a hit shadows only before the light (shadow_t_max=1); literal: the reference's any-hit")
+    ap.add_argument("--accel", default="ploc", choices=["lbvh", "ploc"], help="BVH builder (both on the GPU)")
     ap.add_argument("--photons", type=int, default=0,
                     help="C5: photons per light (0 = off).  The sharded photon pass (emit -> RCCL all-gather -> grid) runs once, "
                          "untimed by `value` and reported as config.photon_pass_ms; frames then shade with radiance_estimate "
@@ -92,7 +93,7 @@ def main():
     W, H = wl["w"], wl["h"]
     scene = scenes.cornell() if wl["tris"] == 0 else scenes.atrium(wl["tris"])
     shadow_t_max = 1.0 if args.shadow_mode == "corrected" else 0.0
-    g = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_LBVH, device=local_rank, profile=1, bounces=2, do_shadows=1,
+    g = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_PLOC if args.accel == "ploc" else rt.ACCEL_LBVH, device=local_rank, profile=1, bounces=2, do_shadows=1,
                  shadow_t_max=shadow_t_max, use_photon_map=1 if args.photons > 0 else 0, photon_estimate=100,
                  photon_radius=1.0, seed=42)
     build_stats = g.stats()
@@ -206,7 +207,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload + ("+photons" if args.photons > 0 else ""), "scene": scene.name, "triangles": scene.num_tris, "width": W, "height": H,
                        "frames_per_step": nframes, "tile": 64, "bounces": 2, "lights": len(scene.lights),
-                       "shadows": args.shadow_mode, "accel": "lbvh", "parallelism": "tiles x%d" % world,
+                       "shadows": args.shadow_mode, "accel": args.accel, "parallelism": "tiles x%d" % world,
                        "rays_per_frame": round(total_rays / args.steps / nframes, 1),
                        "ms_per_frame": round(elapsed / args.steps * 1e3, 3),
                        "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"],

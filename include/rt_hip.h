@@ -82,13 +82,15 @@ typedef struct rt_hit {
 } rt_hit; /* 16 bytes */
 
 enum rt_hip_geometry { RT_HIP_TRIANGLES = 0, RT_HIP_SPHERES = 1 };
-enum rt_hip_accel { RT_HIP_ACCEL_AUTO = 0, RT_HIP_ACCEL_BRUTE = 1, RT_HIP_ACCEL_LBVH = 2 };
+/* LBVH: Morton-split hierarchy (fastest build).  PLOC: agglomerative build over the same Morton
+ * order, topology by surface area (fewer node visits per ray, a few ms more to build). */
+enum rt_hip_accel { RT_HIP_ACCEL_AUTO = 0, RT_HIP_ACCEL_BRUTE = 1, RT_HIP_ACCEL_LBVH = 2, RT_HIP_ACCEL_PLOC = 3 };
 
 /* Constants the reference hard-codes (file:line beside each). */
 typedef struct rt_hip_config {
 	int device;               /* HIP device ordinal */
 	int geometry;             /* rt_hip_geometry: AccelArray-like triangles or AccelSpheres */
-	int accel;                /* rt_hip_accel; AUTO = brute force below 512 triangles, else LBVH */
+	int accel;                /* rt_hip_accel; AUTO = brute force below 512 triangles, else PLOC */
 	int use_model_mat;        /* 1: world space, vertices x model_mat (processRays, rt_raytracer.cpp:466-475)
 	                             0: object space (AccelArray::addMesh, rt_accel_array.cpp:17-32) */
 	float eps_det;            /* reject det <  eps_det.  FLT_EPSILON (rt_raytracer.cpp:18,336) or the

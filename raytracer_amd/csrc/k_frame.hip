@@ -267,7 +267,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
 	int* spill = sv.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
-	grid_for_each(tile8_count(w, h), [&](int64_t j) {
+	grid_for_each(sv, tile8_count(w, h), [&](int64_t j) {
 		const int i = tile8_pixel((int)j, w, h);
 		if (i < 0) return;
 		int x = i % w, y = i / w;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const Node
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
 	int* spill = sv.spill + ((int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x);
 	uint32_t cn = 0, ct = 0, rays = 0;
-	grid_for_each((int64_t)n * sv.num_lights, [&](int64_t idx) {
+	grid_for_each(sv, (int64_t)n * sv.num_lights, [&](int64_t idx) {
 		int light = (int)(idx / n), i = (int)(idx % n);
 		const NodeGeo g = geo[i];
 		if (g.material < 0) return;

@@ -125,6 +125,234 @@ __global__ __launch_bounds__(256) void k_refit(const float4* __restrict__ tri_bo
 	}
 }
 
+
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) ---------------------------
+// Bottom-up agglomeration over the Morton-ordered leaves: every cluster looks `r` places to either
+// side for the neighbour whose union with it has the smallest surface area; mutual nearest
+// neighbours merge; the survivors are compacted in order; repeat until one cluster is left.  The
+// topology follows surface area instead of Morton bits, which is what cuts node visits per ray.
+// Internal node ids are handed out backwards (the k-th merge gets id n-2-k), so the root is node 0
+// and parents sit at lower addresses than their children.
+struct __attribute__((aligned(16))) CBox {
+	float4 lo, hi;  // xyz used
+};
+
+__device__ __forceinline__ float union_half_area(const CBox& a, const CBox& b)
+{
+	float dx = fmaxf(a.hi.x, b.hi.x) - fminf(a.lo.x, b.lo.x);
+	float dy = fmaxf(a.hi.y, b.hi.y) - fminf(a.lo.y, b.lo.y);
+	float dz = fmaxf(a.hi.z, b.hi.z) - fminf(a.lo.z, b.lo.z);
+	return dx * dy + (dy * dz + dz * dx);
+}
+__device__ __forceinline__ CBox union_box(const CBox& a, const CBox& b)
+{
+	CBox u;
+	u.lo = make_float4(fminf(a.lo.x, b.lo.x), fminf(a.lo.y, b.lo.y), fminf(a.lo.z, b.lo.z), 0.0f);
+	u.hi = make_float4(fmaxf(a.hi.x, b.hi.x), fmaxf(a.hi.y, b.hi.y), fmaxf(a.hi.z, b.hi.z), 0.0f);
+	return u;
+}
+__device__ __forceinline__ void store_slot(BoxSlot* s, const CBox& b)
+{
+	s->mn[0] = b.lo.x; s->mn[1] = b.lo.y; s->mn[2] = b.lo.z;
+	s->mx[0] = b.hi.x; s->mx[1] = b.hi.y; s->mx[2] = b.hi.z;
+}
+
+constexpr int PB = 256;       // clusters per block in the grid-wide phases
+constexpr int PR_MAX = 64;    // largest search radius
+constexpr int PTAIL = 1024;   // cluster count at which one workgroup finishes the build in LDS
+
+__global__ __launch_bounds__(256) void k_ploc_init(const float4* __restrict__ tri_box, const uint32_t* __restrict__ order,
+                                                   int n, float pad, BoxSlot* __restrict__ slots, int* __restrict__ cl,
+                                                   CBox* __restrict__ cbox)
+{
+	int j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= n) return;
+	uint32_t prim = order[j];
+	float4 a = tri_box[2 * (size_t)prim], b = tri_box[2 * (size_t)prim + 1];
+	CBox c;
+	c.lo = make_float4(a.x - pad, a.y - pad, a.z - pad, 0.0f);
+	c.hi = make_float4(b.x + pad, b.y + pad, b.z + pad, 0.0f);
+	store_slot(slots + (n - 1) + j, c);
+	cl[j] = ~j;
+	cbox[j] = c;
+}
+
+// Nearest neighbour of cluster i among [i-r, i+r].  Candidate i^1 is examined first and later
+// candidates must be strictly better, so that runs of identical boxes pair up (0,1)(2,3).. instead
+// of forming a chain that merges one pair per round.  force: skip the search, N[i] = i^1.
+__device__ __forceinline__ int ploc_nearest(const CBox* __restrict__ win, int base, int i, int c, int r, int force)
+{
+	int j0 = i ^ 1;
+	if (force) return j0 < c ? j0 : i;
+	const CBox me = win[i - base];
+	float best = __builtin_inff();
+	int bj = i;
+	if (j0 < c) { best = union_half_area(me, win[j0 - base]); bj = j0; }
+	int lo = max(0, i - r), hi = min(c - 1, i + r);
+	for (int j = lo; j <= hi; ++j) {
+		if (j == i || j == j0) continue;
+		float d = union_half_area(me, win[j - base]);
+		if (d < best) { best = d; bj = j; }
+	}
+	return bj;
+}
+
+__global__ __launch_bounds__(PB) void k_ploc_nn(const CBox* __restrict__ cbox, int c, int r, int force, int* __restrict__ nn)
+{
+	__shared__ CBox win[PB + 2 * PR_MAX];
+	const int base = blockIdx.x * PB - r;
+	for (int t = threadIdx.x; t < PB + 2 * r; t += PB) {
+		int g = base + t;
+		if (g >= 0 && g < c) win[t] = cbox[g];
+	}
+	__syncthreads();
+	int i = blockIdx.x * PB + threadIdx.x;
+	if (i < c) nn[i] = ploc_nearest(win, base, i, c, r, force);
+}
+
+// flag: 0 dies (absorbed by its partner), 1 survives unchanged, 2 survives as the new parent node
+__device__ __forceinline__ int ploc_flag(const int* nn, int i, int c)
+{
+	if (i >= c) return 0;
+	int j = nn[i];
+	if (j != i && nn[j] == i) return i < j ? 2 : 0;
+	return 1;
+}
+
+// exclusive prefix over the workgroup of two flags at once; totals in tot_a / tot_b (all threads)
+template <int THREADS>
+__device__ __forceinline__ void block_scan2(bool a, bool b, int& pre_a, int& pre_b, int& tot_a, int& tot_b)
+{
+	__shared__ int wa[THREADS / 64], wb[THREADS / 64];
+	const uint64_t ma = __ballot(a), mb = __ballot(b);
+	const int wave = threadIdx.x >> 6;
+	__syncthreads();  // protect wa/wb against the previous call's readers
+	if ((threadIdx.x & 63) == 0) { wa[wave] = __popcll(ma); wb[wave] = __popcll(mb); }
+	__syncthreads();
+	int ba = 0, bb = 0, ta = 0, tb = 0;
+	for (int w = 0; w < THREADS / 64; ++w) {
+		if (w < wave) { ba += wa[w]; bb += wb[w]; }
+		ta += wa[w]; tb += wb[w];
+	}
+	pre_a = ba + __popcll(ma & lanemask_lt());
+	pre_b = bb + __popcll(mb & lanemask_lt());
+	tot_a = ta; tot_b = tb;
+}
+
+__global__ __launch_bounds__(PB) void k_ploc_count(const int* __restrict__ nn, int c, uint8_t* __restrict__ flag,
+                                                  int2* __restrict__ block_counts)
+{
+	int i = blockIdx.x * PB + threadIdx.x;
+	int f = ploc_flag(nn, i, c);
+	if (i < c) flag[i] = (uint8_t)f;
+	int pa, pb, ta, tb;
+	block_scan2<PB>(f != 0, f == 2, pa, pb, ta, tb);
+	if (threadIdx.x == 0) block_counts[blockIdx.x] = make_int2(ta, tb);
+}
+
+// One workgroup: exclusive scan of the per-block counts in place; totals[0] = survivors.
+__global__ __launch_bounds__(1024) void k_ploc_scan(int2* __restrict__ block_counts, int nb, int* __restrict__ totals)
+{
+	__shared__ int sa[1024], sb[1024];
+	__shared__ int carry_a, carry_b;
+	if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
+	__syncthreads();
+	for (int base = 0; base < nb; base += 1024) {
+		int b = base + threadIdx.x;
+		int2 v = b < nb ? block_counts[b] : make_int2(0, 0);
+		sa[threadIdx.x] = v.x; sb[threadIdx.x] = v.y;
+		__syncthreads();
+		for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+			int xa = threadIdx.x >= off ? sa[threadIdx.x - off] : 0;
+			int xb = threadIdx.x >= off ? sb[threadIdx.x - off] : 0;
+			__syncthreads();
+			sa[threadIdx.x] += xa; sb[threadIdx.x] += xb;
+			__syncthreads();
+		}
+		if (b < nb) block_counts[b] = make_int2(carry_a + sa[threadIdx.x] - v.x, carry_b + sb[threadIdx.x] - v.y);
+		__syncthreads();
+		if (threadIdx.x == 1023) { carry_a += sa[1023]; carry_b += sb[1023]; }
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { totals[0] = carry_a; totals[1] = carry_b; }
+}
+
+__device__ __forceinline__ void ploc_link(int id, int a, int b, int* left, int* right, int* node_parent, int* leaf_parent)
+{
+	left[id] = a; right[id] = b;
+	if (a >= 0) node_parent[a] = id; else leaf_parent[~a] = id;
+	if (b >= 0) node_parent[b] = id; else leaf_parent[~b] = id;
+}
+
+__global__ __launch_bounds__(PB) void k_ploc_merge(const int* __restrict__ cl, const CBox* __restrict__ cbox,
+                                                  const int* __restrict__ nn, const uint8_t* __restrict__ flag,
+                                                  const int2* __restrict__ block_prefix, int c, int n, int created,
+                                                  int* __restrict__ cl_out, CBox* __restrict__ cbox_out,
+                                                  int* __restrict__ left, int* __restrict__ right,
+                                                  int* __restrict__ node_parent, int* __restrict__ leaf_parent,
+                                                  BoxSlot* __restrict__ slots)
+{
+	int i = blockIdx.x * PB + threadIdx.x;
+	int f = i < c ? flag[i] : 0;
+	int pa, pb, ta, tb;
+	block_scan2<PB>(f != 0, f == 2, pa, pb, ta, tb);
+	if (f == 0) return;
+	const int2 bp = block_prefix[blockIdx.x];
+	const int pos = bp.x + pa;
+	if (f == 1) {
+		cl_out[pos] = cl[i];
+		cbox_out[pos] = cbox[i];
+	} else {
+		const int j = nn[i];
+		const int id = (n - 2) - (created + bp.y + pb);
+		ploc_link(id, cl[i], cl[j], left, right, node_parent, leaf_parent);
+		CBox u = union_box(cbox[i], cbox[j]);
+		store_slot(slots + id, u);
+		cl_out[pos] = id;
+		cbox_out[pos] = u;
+	}
+}
+
+// The last rounds (c <= PTAIL) in one workgroup, clusters in LDS.
+__global__ __launch_bounds__(PTAIL) void k_ploc_tail(const int* __restrict__ cl_in, const CBox* __restrict__ cbox_in, int c0,
+                                                    int r, int n, int created0, int* __restrict__ left,
+                                                    int* __restrict__ right, int* __restrict__ node_parent,
+                                                    int* __restrict__ leaf_parent, BoxSlot* __restrict__ slots)
+{
+	__shared__ CBox sbox[2][PTAIL];
+	__shared__ int scl[2][PTAIL];
+	__shared__ int snn[PTAIL];
+	const int i = threadIdx.x;
+	if (i < c0) { sbox[0][i] = cbox_in[i]; scl[0][i] = cl_in[i]; }
+	int c = c0, created = created0, cur = 0, force = 0;
+	__syncthreads();
+	while (c > 1) {
+		if (i < c) snn[i] = ploc_nearest(sbox[cur], 0, i, c, r, force);
+		__syncthreads();
+		const int f = ploc_flag(snn, i, c);
+		int pa, pb, ta, tb;
+		block_scan2<PTAIL>(f != 0, f == 2, pa, pb, ta, tb);
+		if (f == 1) {
+			scl[cur ^ 1][pa] = scl[cur][i];
+			sbox[cur ^ 1][pa] = sbox[cur][i];
+		} else if (f == 2) {
+			const int j = snn[i];
+			const int id = (n - 2) - (created + pb);
+			ploc_link(id, scl[cur][i], scl[cur][j], left, right, node_parent, leaf_parent);
+			CBox u = union_box(sbox[cur][i], sbox[cur][j]);
+			store_slot(slots + id, u);
+			scl[cur ^ 1][pa] = id;
+			sbox[cur ^ 1][pa] = u;
+		}
+		force = (tb == 0);  // no mutual pair (only possible with exact ties): pair neighbours next round
+		created += tb;
+		c = ta;
+		cur ^= 1;
+		__syncthreads();
+	}
+	if (i == 0) node_parent[0] = -1;
+}
+
 __global__ __launch_bounds__(256) void k_emit_nodes(const BoxSlot* __restrict__ slots, int n,
                                                     const int* __restrict__ left, const int* __restrict__ right,
                                                     const int* __restrict__ node_parent, BvhNode* __restrict__ nodes)
@@ -165,6 +393,52 @@ __global__ __launch_bounds__(256) void k_depth(const int* __restrict__ node_pare
 
 }  // namespace
 
+// PLOC rounds on the sorted leaves: fills left/right/node_parent/leaf_parent and every node's box slot.
+static int build_ploc(rt_hip_ctx* ctx, int n, float pad, const uint32_t* order, int* left, int* right,
+                      int* node_parent, int* leaf_parent, BoxSlot* slots)
+{
+	hipStream_t st = ctx->stream;
+	int r = 16;
+	if (const char* e = getenv("RT_HIP_PLOC_RADIUS")) r = std::min(PR_MAX, std::max(1, atoi(e)));
+	const int nb0 = (n + PB - 1) / PB;
+	// scratch: 2 cluster lists, 2 cluster box lists, nn, flag, block counts, totals
+	size_t bytes = (size_t)n * (2 * 4 + 2 * sizeof(CBox) + 4 + 1) + (size_t)nb0 * sizeof(int2) + 256 + 64;
+	RT_CHECK(ctx->d_ploc.reserve(bytes));
+	char* base = ctx->d_ploc.as<char>();
+	CBox* cbox[2] = {(CBox*)base, (CBox*)base + n};
+	int* cl[2] = {(int*)(cbox[1] + n), (int*)(cbox[1] + n) + n};
+	int* nn = cl[1] + n;
+	int2* block_counts = (int2*)(nn + n);
+	int* totals = (int*)(block_counts + nb0 + 1);
+	uint8_t* flag = (uint8_t*)(totals + 16);
+	hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad,
+	                   slots, cl[0], cbox[0]);
+	int c = n, created = 0, cur = 0, force = 0, rounds = 0;
+	int* h_tot = (int*)ctx->h_small;
+	while (c > PTAIL) {
+		const int nb = (c + PB - 1) / PB;
+		hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(PB), 0, st, cbox[cur], c, r, force, nn);
+		hipLaunchKernelGGL(k_ploc_count, dim3(nb), dim3(PB), 0, st, nn, c, flag, block_counts);
+		hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, totals);
+		hipLaunchKernelGGL(k_ploc_merge, dim3(nb), dim3(PB), 0, st, cl[cur], cbox[cur], nn, flag, block_counts, c, n, created,
+		                   cl[cur ^ 1], cbox[cur ^ 1], left, right, node_parent, leaf_parent, slots);
+		RT_HIP_CHECK(hipGetLastError());
+		RT_HIP_CHECK(hipMemcpyAsync(h_tot, totals, 8, hipMemcpyDeviceToHost, st));
+		RT_HIP_CHECK(hipStreamSynchronize(st));
+		const int c_next = h_tot[0];
+		if (c_next > c || c_next < (c + 1) / 2) { rt_set_error("PLOC round produced %d clusters from %d", c_next, c); return RT_HIP_ERR_STATE; }
+		// no progress is only possible with exact distance ties; a forced round pairs neighbours
+		force = (c_next == c || ++rounds > 512) ? 1 : 0;
+		created += c - c_next;
+		c = c_next;
+		cur ^= 1;
+	}
+	hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(PTAIL), 0, st, cl[cur], cbox[cur], c, r, n, created, left, right,
+	                   node_parent, leaf_parent, slots);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
 int rt_build_lbvh(rt_hip_ctx* ctx)
 {
 	hipStream_t st = ctx->stream;
@@ -203,10 +477,15 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 	RT_CHECK(ctx->d_misc.reserve((size_t)(2 * n) * sizeof(BoxSlot)));
 	BoxSlot* slots = ctx->d_misc.as<BoxSlot>();
 
-	hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, st, keys, n, left, right, node_parent, leaf_parent);
 	float pad = 1e-5f * emax;
-	hipLaunchKernelGGL(k_refit, dim3(g), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad, left, right,
-	                   node_parent, leaf_parent, slots, arrive);
+	const bool ploc = ctx->cfg.accel == RT_HIP_ACCEL_PLOC || (ctx->cfg.accel == RT_HIP_ACCEL_AUTO && rt_auto_ploc());
+	if (ploc) {
+		RT_CHECK(build_ploc(ctx, n, pad, order, left, right, node_parent, leaf_parent, slots));
+	} else {
+		hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, st, keys, n, left, right, node_parent, leaf_parent);
+		hipLaunchKernelGGL(k_refit, dim3(g), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad, left, right,
+		                   node_parent, leaf_parent, slots, arrive);
+	}
 	RT_CHECK(ctx->d_nodes.reserve((size_t)(n - 1) * sizeof(BvhNode)));
 	hipLaunchKernelGGL(k_emit_nodes, dim3(g), dim3(256), 0, st, slots, n, left, right, node_parent,
 	                   ctx->d_nodes.as<BvhNode>());
@@ -224,7 +503,7 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 	ctx->num_nodes = n - 1;
 	if (depth + 1 > 96) {
 		// pathological (massively duplicated centres): fall back to brute force rather than overflow
-		rt_set_error("LBVH depth %d exceeds the traversal stack limit (96)", depth);
+		rt_set_error("BVH depth %d exceeds the traversal stack limit (96)", depth);
 		return RT_HIP_ERR_LIMIT;
 	}
 	// overflow part of the traversal stacks: entries beyond the LDS-resident ones, one column per

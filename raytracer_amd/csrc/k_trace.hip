@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void k_bvh(SceneView sv, const float* __
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
 	int* spill = sv.spill + (blockIdx.x * BVH_BLOCK + threadIdx.x);
 	uint32_t cn = 0, ct = 0, rays = 0;
-	grid_for_each(n, [&](int64_t i) {
+	grid_for_each(sv, n, [&](int64_t i) {
 		f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
 		Hit best;
 		uint32_t a = 0, b = 0;

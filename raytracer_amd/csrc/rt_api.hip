@@ -76,6 +76,20 @@ size_t rt_debug_extra_lds()
 	return (size_t)v;
 }
 
+int rt_xcd_chunk()
+{
+	static int v = -1;
+	if (v < 0) { const char* e = getenv("RT_HIP_XCD_CHUNK"); v = e ? std::max(0, atoi(e)) : 0; }
+	return v;
+}
+
+bool rt_auto_ploc()
+{
+	static int v = -1;
+	if (v < 0) { const char* e = getenv("RT_HIP_AUTO_PLOC"); v = e ? atoi(e) : 1; }
+	return v != 0;
+}
+
 int rt_lds_depth()
 {
 	static int v = -1;
@@ -86,8 +100,10 @@ int rt_lds_depth()
 int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block)
 {
 	int64_t need = (work_items + block - 1) / block;
-	int64_t cap = std::max<int64_t>(1, (int64_t)ctx->max_trace_threads / block);
-	return (int)std::max<int64_t>(1, std::min(need, cap));
+	// a multiple of 8 * xcd_chunk, so that the XCD-aware renumbering of the blocks is a bijection
+	const int64_t unit = 8 * std::max(1, rt_xcd_chunk());
+	int64_t cap = std::max<int64_t>(unit, (int64_t)ctx->max_trace_threads / block / unit * unit);
+	return (int)std::min((std::max<int64_t>(need, 1) + unit - 1) / unit * unit, cap);
 }
 
 size_t rt_trace_lds(const SceneView& sv, int block)
@@ -114,6 +130,7 @@ SceneView rt_scene_view(const rt_hip_ctx* ctx)
 	sv.lds_depth = std::min(sv.stack_depth, rt_lds_depth());
 	sv.spill = ctx->d_spill.as<int>();
 	sv.spill_stride = ctx->max_trace_threads;
+	sv.xcd_chunk = rt_xcd_chunk();
 	sv.tp.eps_det = ctx->cfg.eps_det;
 	sv.tp.eps_t = ctx->cfg.eps_t;
 	sv.tp.t_max = ctx->cfg.t_max;
@@ -280,7 +297,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_hits, &ctx->d_occ, &ctx->d_in_a, &ctx->d_in_b, &ctx->d_records, &ctx->d_offsets, &ctx->d_keys,
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
-	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill};
+	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);

@@ -70,7 +70,8 @@ struct SceneView {
 	int stack_depth;  // required traversal stack entries (BVH depth + 1)
 	int lds_depth;    // entries [0, lds_depth) of a lane's stack live in LDS, the rest in `spill`
 	int* spill;       // [stack_depth - lds_depth][spill_stride] ints in HBM (nullptr if not needed)
-	int spill_stride; // = maximum number of threads of a trace launch (persistent grid)
+	int spill_stride; // = maximum number of threads of a trace launch
+	int xcd_chunk;    // XCD-aware block renumbering (rt_trace_dev.h); 0 = hardware order
 	TraceParams tp;
 };
 
@@ -94,7 +95,7 @@ struct rt_hip_ctx {
 	// geometry in HBM
 	DevBuf d_verts, d_normals, d_texcoords, d_faces, d_mesh_of_tri, d_mesh_xf;  // inputs of the soup kernel
 	DevBuf d_tri_pos, d_tri_attr, d_tri_isect, d_tri_box, d_nodes, d_spheres, d_materials, d_lights;
-	DevBuf d_morton, d_morton_tmp, d_order, d_order_tmp, d_hist, d_flags, d_parent_leaf, d_bounds, d_misc;
+	DevBuf d_morton, d_morton_tmp, d_order, d_order_tmp, d_hist, d_flags, d_parent_leaf, d_bounds, d_misc, d_ploc;
 	int num_tris = 0, num_nodes = 0, bvh_depth = 0, use_bvh = 0;
 	float bounds[6];
 
@@ -120,6 +121,8 @@ struct rt_hip_ctx {
 
 SceneView rt_scene_view(const rt_hip_ctx* ctx);
 size_t rt_debug_extra_lds();
+bool rt_auto_ploc();           // RT_HIP_AUTO_PLOC: what ACCEL_AUTO builds
+int rt_xcd_chunk();            // RT_HIP_XCD_CHUNK
 int rt_lds_depth();           // RT_HIP_LDS_DEPTH, default 16
 constexpr int RT_TRACE_OVERSUB = 4;
 // Launch shape of the trace kernels: blocks of `block` threads, at most ctx->max_trace_threads in

@@ -35,11 +35,26 @@ __device__ __forceinline__ int stack_pop(const SceneView& sv, const lds_int* sta
 // balancing of uneven rays to the hardware dispatcher.  Measured on MI355X (atrium-262k, shadow
 // rays): 1x 0.765 ms, 2x 0.657 ms, 4x 0.586 ms, uncapped 0.594 ms; a software queue (one returning
 // atomic per wave per 64 rays) was atomic-bound at 1.08 ms.
+// XCD-aware block order: workgroups are dealt round robin to the 8 XCDs (block b runs on XCD
+// b % 8), each with an L2 of its own.  Renumbering b -> (b % 8) * ceil(nb / 8) + b / 8 hands every
+// XCD one contiguous eighth of each grid-sized slice of the items, so that its L2 holds the part of
+// the BVH under one region of the frame rather than a thin sample of all of it.
+__device__ __forceinline__ int64_t xcd_block_index(int chunk)
+{
+	// groups of 8 * chunk consecutive block numbers; inside a group XCD x takes numbers
+	// [x * chunk, (x + 1) * chunk).  A bijection on [0, nb) when nb is a multiple of 8 * chunk;
+	// chunk == 0 keeps the hardware order.
+	const int64_t b = blockIdx.x;
+	if (chunk <= 0) return b;
+	const int64_t q = b >> 3, x = b & 7;
+	return (q / chunk) * (8 * chunk) + x * chunk + (q % chunk);
+}
+
 template <typename F>
-__device__ __forceinline__ void grid_for_each(int64_t total, F&& body)
+__device__ __forceinline__ void grid_for_each(const SceneView& sv, int64_t total, F&& body)
 {
 	const int64_t gsize = (int64_t)gridDim.x * blockDim.x;
-	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gsize) body(i);
+	for (int64_t i = xcd_block_index(sv.xcd_chunk) * blockDim.x + threadIdx.x; i < total; i += gsize) body(i);
 }
 
 template <bool ANY, bool CENSUS>
@@ -53,34 +68,31 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 	bool found = false;
 	if (sv.num_tris > 0) {
 		const RayPre rp = ray_pre(O, D);
+		// One loop, node or leaf per iteration ("if-if").  Measured against "while-while" (inner loop
+		// over internal nodes, leaves batched per wave) on MI355X: 0.563 ms vs 0.681 ms for the shadow
+		// rays of atrium-262k -- on 64-wide waves the lanes parked at a leaf cost more than the masked
+		// triangle code does.
 		// num_tris == 1: no internal node; the root "node" is leaf slot 0.
+		const int EXIT = 0x7fffffff;
 		int cur = (sv.num_tris == 1) ? ~0 : 0;
 		int sp = 0;
-		const int SENTINEL = 0x7fffffff;
-		while (cur != SENTINEL) {
+		while (cur != EXIT) {
+			bool pop;
 			if (cur >= 0) {
 				const float4* np = (const float4*)(sv.nodes + cur);
 				float4 q0 = np[0], q1 = np[1], q2 = np[2];
-				int4 q3 = *((const int4*)(np + 3));
+				int2 ch = *((const int2*)(np + 3));
 				if (CENSUS) ++cnt_nodes;
 				float tl, tr;
 				bool hl, hr;
 				slab2(rp, q0, q1, q2, ANY ? sv.tp.t_max : best.t, hl, hr, tl, tr);
+				const bool right_first = hr && (!hl || tr < tl);
 				if (hl && hr) {
-					bool left_first = tl <= tr;
-					int nearc = left_first ? q3.x : q3.y;
-					int farc = left_first ? q3.y : q3.x;
-					stack_push(sv, stack, stride, spill, sp, farc);
+					stack_push(sv, stack, stride, spill, sp, right_first ? ch.x : ch.y);
 					++sp;
-					cur = nearc;
-				} else if (hl) {
-					cur = q3.x;
-				} else if (hr) {
-					cur = q3.y;
-				} else {
-					if (sp == 0) cur = SENTINEL;
-					else { --sp; cur = stack_pop(sv, stack, stride, spill, sp); }
 				}
+				cur = right_first ? ch.y : ch.x;
+				pop = !(hl || hr);
 			} else {
 				const TriIsect* tp = sv.tris + (~cur);
 				float4 a = tp->a, b = tp->b, c = tp->c;
@@ -91,7 +103,10 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 				} else {
 					if (mt_closest(O, D, v0, e1, e2, __float_as_uint(a.w), sv.tp, best)) found = true;
 				}
-				if (sp == 0) cur = SENTINEL;
+				pop = true;
+			}
+			if (pop) {
+				if (sp == 0) cur = EXIT;
 				else { --sp; cur = stack_pop(sv, stack, stride, spill, sp); }
 			}
 		}

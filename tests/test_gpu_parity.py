@@ -32,7 +32,7 @@ def rt():
 
 
 @pytest.mark.parametrize("scene_fn", [scenes.cornell, lambda: scenes.atrium(2048)], ids=["cornell", "atrium2k"])
-@pytest.mark.parametrize("accel", [1, 2], ids=["brute", "lbvh"])
+@pytest.mark.parametrize("accel", [1, 2, 3], ids=["brute", "lbvh", "ploc"])
 def test_array_intersect(rt, oracle_cls, scene_fn, accel):
     sc = scene_fn()
     orc = oracle_cls(sc)
@@ -133,10 +133,11 @@ def test_process_rays_cornell(rt, oracle_cls, accel):
     g.close()
 
 
-def test_process_rays_atrium_lbvh(rt, oracle_cls):
+@pytest.mark.parametrize("accel", [2, 3], ids=["lbvh", "ploc"])
+def test_process_rays_atrium_lbvh(rt, oracle_cls, accel):
     sc = scenes.atrium(8192)
     orc = oracle_cls(sc)
-    g = rt.RtHip(sc, accel=2)
+    g = rt.RtHip(sc, accel=accel)
     a, b, same = _check_process(sc, orc, g, 160, 120)
     _check_groups(sc, a, b, same)
     st = g.stats()
@@ -176,10 +177,13 @@ def test_process_rays_edge_cases(rt, oracle_cls):
     g.close()
 
 
-def test_bvh_structure(rt):
-    sc = scenes.atrium(8192)
-    g = rt.RtHip(sc, accel=2)
+@pytest.mark.parametrize("accel,tris", [(2, 8192), (3, 8192), (3, 700), (3, 40000)],
+                         ids=["lbvh", "ploc", "ploc-one-workgroup", "ploc-40k"])
+def test_bvh_structure(rt, accel, tris):
+    sc = scenes.atrium(tris)
+    g = rt.RtHip(sc, accel=accel)
     nodes, prims = g.get_bvh()
+    assert nodes.shape[0] == prims.shape[0] - 1
     n = prims.shape[0]
     assert sorted(prims.tolist()) == list(range(n))
     left = nodes[:, 12].view(np.int32)
