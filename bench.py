@@ -173,26 +173,38 @@ def main():
     tris_clo = cs["census_tris_closest"] / max(cs["census_rays_closest"], 1)
     bytes_per_any = 64.0 * nodes_any + 48.0 * tris_any + 48.0
     bytes_per_clo = 64.0 * nodes_clo + 48.0 * tris_clo + 48.0
-    dominant = "k_shadow(any-hit)" if any_ms >= clo_ms else "k_bvh(closest)"
-    if any_ms >= clo_ms:
+    fused = clo_launches == 0 and rays_clo > 0   # the frame driver folds the closest-hit queues into the shadow launches
+    if fused:
+        dominant = "k_shadow (shadow any-hit rays + the level's closest-hit queue in the same launch)"
+        launches = max(any_launches, 1)
+        rays_per_launch = (rays_any + rays_clo) / launches
+        avg_ms = any_ms / launches
+        bytes_per_launch = (rays_any * bytes_per_any + rays_clo * bytes_per_clo) / launches
+        bpr = bytes_per_launch / max(rays_per_launch, 1)
+        nodes_dom = (rays_any * nodes_any + rays_clo * nodes_clo) / max(rays_any + rays_clo, 1)
+        tris_dom = (rays_any * tris_any + rays_clo * tris_clo) / max(rays_any + rays_clo, 1)
+    elif any_ms >= clo_ms:
+        dominant = "k_shadow (any-hit)"
         rays_per_launch = rays_any / max(any_launches, 1)
         avg_ms = any_ms / max(any_launches, 1)
-        bpr = bytes_per_any
+        bpr, nodes_dom, tris_dom = bytes_per_any, nodes_any, tris_any
     else:
+        dominant = "k_bvh (closest-hit)"
         rays_per_launch = rays_clo / max(clo_launches, 1)
         avg_ms = clo_ms / max(clo_launches, 1)
-        bpr = bytes_per_clo
+        bpr, nodes_dom, tris_dom = bytes_per_clo, nodes_clo, tris_clo
     achieved = (rays_per_launch * bpr) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel": dominant, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": round(rays_per_launch, 1),
-                "nodes_per_ray": round(nodes_any if any_ms >= clo_ms else nodes_clo, 2),
-                "tris_per_ray": round(tris_any if any_ms >= clo_ms else tris_clo, 2),
+                "nodes_per_ray": round(nodes_dom, 2), "tris_per_ray": round(tris_dom, 2),
                 "bytes_per_ray": round(bpr, 1),
                 "kernel_mrays_per_s": round(rays_per_launch / (avg_ms * 1e-3) / 1e6, 1) if avg_ms > 0 else 0.0,
-                "closest": {"avg_launch_ms": round(clo_ms / max(clo_launches, 1), 4),
-                            "rays_per_launch": round(rays_clo / max(clo_launches, 1), 1),
-                            "nodes_per_ray": round(nodes_clo, 2), "tris_per_ray": round(tris_clo, 2)}}
+                "any_hit": {"rays_per_frame": round(rays_any / max(st["frames"], 1), 1), "nodes_per_ray": round(nodes_any, 2),
+                            "tris_per_ray": round(tris_any, 2)},
+                "closest": {"rays_per_frame": round(rays_clo / max(st["frames"], 1), 1), "nodes_per_ray": round(nodes_clo, 2),
+                            "tris_per_ray": round(tris_clo, 2), "standalone_launches": clo_launches,
+                            "avg_launch_ms": round(clo_ms / max(clo_launches, 1), 4)}}
 
     # ---- CPU baseline on rank 0 (N = 1 only) ------------------------------------------------
     cpu_baseline = None

@@ -105,9 +105,20 @@ __device__ __forceinline__ void resolve_tri(const SceneView& sv, const Hit& h, H
 	}
 }
 
-__global__ __launch_bounds__(BLOCK) void k_resolve(SceneView sv, const Hit* __restrict__ hits, int n,
-                                                   HitInfo* __restrict__ out)
+// Count convention of the frame kernels: `n` is the item count, or -- when n_ptr != nullptr -- the
+// capacity, and the count is min(n, *n_ptr) read on the device (the sync-free frame path never
+// brings a count back to the host between launches).
+__device__ __forceinline__ int dev_count(int n, const int* __restrict__ n_ptr)
 {
+	if (!n_ptr) return n;
+	int m = *n_ptr;
+	return m < n ? m : n;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_resolve(SceneView sv, const Hit* __restrict__ hits, int n,
+                                                   const int* __restrict__ n_ptr, HitInfo* __restrict__ out)
+{
+	n = dev_count(n, n_ptr);
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
 	HitInfo hi;
@@ -367,18 +378,47 @@ __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__
 
 // Shadow rays: one lane per (light, node); lanes of a wave share the light, so the rays of a
 // wave converge on one point.  occl[node] gets bit `light` when the ray is blocked.
+// Optionally the launch also carries a queue of closest-hit rays (the level's reflection or
+// refraction rays): every thread first takes its share of that queue, then of the shadow rays.  On
+// its own such a queue is a short, latency-bound launch (one generation of waves, as slow as its
+// slowest ray); inside the shadow launch its stalls are covered by shadow-ray work.
+struct FusedQueue {
+	const float* org;      // nullptr: no queue
+	const float* dir;
+	const int* count_ptr;  // count on the device (nullptr: `capacity` is the count)
+	int capacity;
+	Hit* hits;
+	unsigned long long* census;
+};
+
 template <bool CENSUS>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const NodeGeo* __restrict__ geo, int n,
+                                                        const int* __restrict__ n_ptr, int light_lo, int light_hi,
                                                         float shadow_t_max, unsigned int* __restrict__ occl,
-                                                        unsigned long long* census)
+                                                        unsigned long long* census, FusedQueue fq)
 {
-	if (shadow_t_max > 0.0f) sv.tp.t_max = shadow_t_max;
+	n = dev_count(n, n_ptr);
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
 	int* spill = sv.spill + ((int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x);
+	if (fq.org) {
+		const int nq = dev_count(fq.capacity, fq.count_ptr);
+		uint32_t cn = 0, ct = 0, rays = 0;
+		grid_for_each(sv, nq, [&](int64_t i) {
+			f3 O = ld3(fq.org + 3 * (size_t)i), D = ld3(fq.dir + 3 * (size_t)i);
+			Hit best;
+			uint32_t a = 0, b = 0;
+			if (sv.use_bvh) bvh_trace<false, CENSUS>(sv, O, D, best, stack, TRACE_BLOCK, spill, a, b);
+			else brute_trace<false>(sv, O, D, best);
+			cn += a; ct += b; ++rays;
+			fq.hits[i] = best;
+		});
+		if (CENSUS && fq.census) census_add(fq.census, cn, ct, rays);
+	}
+	if (shadow_t_max > 0.0f) sv.tp.t_max = shadow_t_max;
 	uint32_t cn = 0, ct = 0, rays = 0;
-	grid_for_each(sv, (int64_t)n * sv.num_lights, [&](int64_t idx) {
-		int light = (int)(idx / n), i = (int)(idx % n);
+	grid_for_each(sv, (int64_t)n * (light_hi - light_lo), [&](int64_t idx) {
+		int light = light_lo + (int)(idx / n), i = (int)(idx % n);
 		const NodeGeo g = geo[i];
 		if (g.material < 0) return;
 		++rays;
@@ -406,15 +446,33 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_shadow(SceneView sv, const Node
 	if (CENSUS && census) census_add(census, cn, ct, rays);
 }
 
+// light_color() without a photon map (rt_raytracer.cpp:98-123): lambert accumulated and clamped
+// light by light, -0.4 per occluded light (Q8).
+__device__ __forceinline__ float light_factor(const SceneView& sv, f3 V, f3 N, unsigned int oc)
+{
+	float lambert = 0.0f, shadow = 1.0f;
+	for (int l = 0; l < sv.num_lights; ++l) {
+		f3 L = ld3(sv.lights[l].position) - V;
+		lambert += dot3(N, normalized3(L));
+		lambert = fminf(fmaxf(lambert, 0.0f), 1.0f);
+		if ((oc >> l) & 1u) shadow = (float)fmax((double)shadow - 0.4, 0.0);
+	}
+	return shadow * lambert;
+}
+
 // Per node: lambert / shadow -> F, and the reflection ray if this level may recurse.
+// defer_light: F is left to k_combine (the shadow rays of this level may still be in flight on the
+// side stream); only the gate and the reflection rays are produced here.
 __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, const NodeGeo* __restrict__ geo,
                                                                NodeShade* __restrict__ shade, int n,
+                                                               const int* __restrict__ n_ptr,
                                                                const unsigned int* __restrict__ occl,
                                                                const float* __restrict__ photon_rgb, int do_shadows,
-                                                               int recurse, int* __restrict__ gate,
+                                                               int defer_light, int recurse, int* __restrict__ gate,
                                                                float* __restrict__ q_org, float* __restrict__ q_dir,
                                                                int* __restrict__ q_parent, int* __restrict__ q_count)
 {
+	n = dev_count(n, n_ptr);
 	int i = blockIdx.x * CBLOCK + threadIdx.x;
 	bool emit = false;
 	f3 V = mk3(0, 0, 0), R = mk3(0, 0, 0);
@@ -429,16 +487,10 @@ __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, co
 			const MaterialRec m = sv.materials[g.material];
 			if (photon_rgb) {
 				st3(s.F, ld3(photon_rgb + 3 * (size_t)i));  // shadow == 1
+			} else if (defer_light) {
+				st3(s.F, mk3(0, 0, 0));
 			} else {
-				float lambert = 0.0f, shadow = 1.0f;
-				unsigned int oc = (do_shadows && occl) ? occl[i] : 0u;
-				for (int l = 0; l < sv.num_lights; ++l) {
-					f3 L = ld3(sv.lights[l].position) - V;
-					lambert += dot3(N, normalized3(L));
-					lambert = fminf(fmaxf(lambert, 0.0f), 1.0f);
-					if ((oc >> l) & 1u) shadow = (float)fmax((double)shadow - 0.4, 0.0);
-				}
-				float f = shadow * lambert;
+				float f = light_factor(sv, V, N, (do_shadows && occl) ? occl[i] : 0u);
 				st3(s.F, mk3(f, f, f));
 			}
 			gate[i] = g.material;
@@ -463,10 +515,11 @@ __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, co
 
 // Refraction spawn: gated by the (possibly overwritten, quirk Q9) material.
 __global__ __launch_bounds__(CBLOCK) void k_spawn_refract(SceneView sv, const NodeGeo* __restrict__ geo, int n,
-                                                         const int* __restrict__ gate, float* __restrict__ q_org,
+                                                         const int* __restrict__ n_ptr, const int* __restrict__ gate, float* __restrict__ q_org,
                                                          float* __restrict__ q_dir, int* __restrict__ q_parent,
                                                          int* __restrict__ q_count)
 {
+	n = dev_count(n, n_ptr);
 	int i = blockIdx.x * CBLOCK + threadIdx.x;
 	bool emit = false;
 	f3 V = mk3(0, 0, 0), T = mk3(0, 0, 0);
@@ -498,8 +551,9 @@ __global__ __launch_bounds__(CBLOCK) void k_spawn_refract(SceneView sv, const No
 
 // Sphere closest for the queue (AccelSpheres::intersect semantics: Ro = direction, first in list).
 __global__ __launch_bounds__(BLOCK) void k_queue_sphere_hits(SceneView sv, const float* __restrict__ q_dir, int nq,
-                                                             HitInfo* __restrict__ out)
+                                                             const int* __restrict__ n_ptr, HitInfo* __restrict__ out)
 {
+	nq = dev_count(nq, n_ptr);
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= nq) return;
 	f3 Rd = ld3(q_dir + 3 * (size_t)i);
@@ -518,10 +572,13 @@ __global__ __launch_bounds__(BLOCK) void k_queue_sphere_hits(SceneView sv, const
 
 // Turn the resolved hits of a queue into child nodes of the next level.
 __global__ __launch_bounds__(CBLOCK) void k_make_children(const HitInfo* __restrict__ hi, const float* __restrict__ q_dir,
-                                                         const int* __restrict__ q_parent, int nq, int branch,
+                                                         const int* __restrict__ q_parent, int nq,
+                                                         const int* __restrict__ n_ptr, int branch,
                                                          int* __restrict__ gate, NodeGeo* __restrict__ child_geo,
-                                                         int* __restrict__ child_count)
+                                                         int* __restrict__ child_count, int child_capacity,
+                                                         int* __restrict__ overflow)
 {
+	nq = dev_count(nq, n_ptr);
 	int i = blockIdx.x * CBLOCK + threadIdx.x;
 	bool hit = false;
 	HitInfo h;
@@ -531,6 +588,7 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(const HitInfo* __restr
 		if (hit && branch == 0) gate[q_parent[i]] = h.material;  // Q9: reflection hit overwrites `material`
 	}
 	int slot = block_compact_slot(hit, child_count);
+	if (hit && slot >= child_capacity) { *overflow = 1; hit = false; }  // the host re-renders with exact sizes
 	if (hit) {
 		NodeGeo g;
 		for (int k = 0; k < 3; ++k) { g.V[k] = h.pos[k]; g.N[k] = h.nrm[k]; g.I[k] = q_dir[3 * (size_t)i + k]; }
@@ -544,10 +602,13 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(const HitInfo* __restr
 // Bottom-up combine of one level: color = (shadow*light) * ((kd*diff + ref*refc) + alpha*refrc)
 // (rt_raytracer.cpp:158).  Level 0 writes RGBA8 as renderScene does (rt_raytracer.cpp:175-185).
 __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* __restrict__ geo,
-                                                   const NodeShade* __restrict__ shade, int n, int level,
+                                                   const NodeShade* __restrict__ shade, int n,
+                                                   const int* __restrict__ n_ptr, int level,
                                                    NodeShade* __restrict__ parent_shade, uint8_t* __restrict__ rgba,
-                                                   float* __restrict__ rgb_float)
+                                                   float* __restrict__ rgb_float, int lit,
+                                                   const unsigned int* __restrict__ occl)
 {
+	n = dev_count(n, n_ptr);
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
 	const NodeGeo g = geo[i];
@@ -559,7 +620,12 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 		float ref = m.reflectivity, alpha = m.alpha;
 		float kd = (float)(1.0 - (double)ref - (double)alpha);
 		f3 mix = (ld3(m.diffuse) * kd + ld3(s.refc) * ref) + ld3(s.refrc) * alpha;
-		col = mk3(s.F[0] * mix.x, s.F[1] * mix.y, s.F[2] * mix.z);
+		f3 F = ld3(s.F);
+		if (lit) {  // deferred light_color(): the level's shadow rays have landed by now
+			float f = light_factor(sv, ld3(g.V), ld3(g.N), occl ? occl[i] : 0u);
+			F = mk3(f, f, f);
+		}
+		col = mk3(F.x * mix.x, F.y * mix.y, F.z * mix.z);
 	}
 	if (level > 0) {
 		float* dst = g.branch == 0 ? parent_shade[g.parent].refc : parent_shade[g.parent].refrc;
@@ -801,35 +867,217 @@ int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgb
 }
 
 // Resolve the hits of a ray queue into HitInfo (triangles via the trace kernels, spheres inline).
+// d_count != nullptr: nq is the queue's capacity and the count stays on the device (the caller
+// accounts for the rays in the stats once it has read the counts back).
 static int trace_queue(rt_hip_ctx* ctx, const SceneView& sv, const float* q_org, const float* q_dir, int nq,
-                       HitInfo* d_hi)
+                       HitInfo* d_hi, const int* d_count = nullptr)
 {
 	if (nq <= 0) return RT_HIP_OK;
 	if (sv.num_spheres > 0 && sv.num_tris == 0) {
-		hipLaunchKernelGGL(k_queue_sphere_hits, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, q_dir, nq, d_hi);
+		hipLaunchKernelGGL(k_queue_sphere_hits, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, q_dir, nq, d_count, d_hi);
 		RT_HIP_CHECK(hipGetLastError());
-		ctx->stats.rays_closest += nq;
+		if (!d_count) ctx->stats.rays_closest += nq;
 		return RT_HIP_OK;
 	}
 	RT_CHECK(ctx->d_hits.reserve((size_t)nq * sizeof(Hit)));
-	RT_CHECK(rt_launch_closest(ctx, q_org, q_dir, nq, ctx->d_hits.as<Hit>()));
-	hipLaunchKernelGGL(k_resolve, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, ctx->d_hits.as<Hit>(), nq, d_hi);
+	RT_CHECK(rt_launch_closest(ctx, q_org, q_dir, nq, ctx->d_hits.as<Hit>(), d_count));
+	hipLaunchKernelGGL(k_resolve, dim3(nblocks(nq, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, ctx->d_hits.as<Hit>(), nq, d_count, d_hi);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }
 
+// ---- the frame without host round trips -----------------------------------------------------------
+// Every level's buffers are sized by what the level can hold at most (2 children per node, capped
+// at FRAME_LEVEL_CAP), the kernels are launched over that bound and read the actual counts on the
+// device, and the host reads all counts once, after the last kernel.  If a level would have needed
+// more than its capacity, *overflowed is set and the caller renders the frame again on the
+// synchronous path, which sizes every level exactly.
+constexpr int64_t FRAME_LEVEL_CAP = (int64_t)1 << 23;      // nodes per level
+constexpr int64_t FRAME_TOTAL_CAP = (int64_t)3 << 23;      // nodes per frame (about 2.5 GB of level arrays)
+
+static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
+                              int rank, int nranks, uint8_t* d_rgba, bool* overflowed, bool* declined)
+{
+	*overflowed = false;
+	*declined = true;
+	hipStream_t st = ctx->stream;
+	SceneView sv = rt_scene_view(ctx);
+	const int bounces = ctx->cfg.bounces;
+	const int n0 = tile8_count(w, h);
+	std::vector<int64_t> cap(bounces), off(bounces + 1, 0);
+	for (int L = 0; L < bounces; ++L) {
+		cap[L] = L == 0 ? n0 : std::min<int64_t>(2 * cap[L - 1], FRAME_LEVEL_CAP);
+		off[L + 1] = off[L] + cap[L];
+	}
+	if (n0 > FRAME_LEVEL_CAP || off[bounces] > FRAME_TOTAL_CAP) return RT_HIP_OK;  // too big to size by bounds
+	*declined = false;
+	const int64_t maxcap = *std::max_element(cap.begin(), cap.end());
+	RT_CHECK(ctx->d_nodes_a.reserve((size_t)off[bounces] * sizeof(NodeGeo)));
+	RT_CHECK(ctx->d_nodes_b.reserve((size_t)off[bounces] * sizeof(NodeShade)));
+	RT_CHECK(ctx->d_gate.reserve((size_t)off[bounces] * sizeof(int)));
+	RT_CHECK(ctx->d_rays_q.reserve((size_t)maxcap * 24));
+	RT_CHECK(ctx->d_ray_parent.reserve((size_t)maxcap * 4));
+	RT_CHECK(ctx->d_records.reserve((size_t)maxcap * sizeof(HitInfo)));
+	RT_CHECK(ctx->d_hits.reserve((size_t)maxcap * sizeof(Hit)));
+	// frame counters: [0] active level-0 nodes, [1] overflow flag,
+	// [8 + 8L + 0] nodes of level L, [.. + 1] reflection rays of level L, [.. + 2] refraction rays
+	const int nfc = 8 + 8 * (bounces + 1);
+	RT_CHECK(ctx->d_qcount.reserve((size_t)nfc * 4));
+	int* fc = ctx->d_qcount.as<int>();
+	float* q_org = ctx->d_rays_q.as<float>();
+	float* q_dir = q_org + (size_t)maxcap * 3;
+	int* q_parent = ctx->d_ray_parent.as<int>();
+	HitInfo* d_hi = ctx->d_records.as<HitInfo>();
+	const bool shadows = !ctx->cfg.use_photon_map && ctx->cfg.do_shadows && sv.num_lights > 0;
+
+	// Order of a level: spawn the reflection rays; launch A = reflection queue + the shadow rays of
+	// the first half of the lights; children; spawn the refraction rays (gated by the reflection
+	// hits, Q9); launch B = refraction queue + the shadow rays of the other lights; children.  The
+	// light term needs all shadow rays of the level, so it is evaluated in k_combine at the end.
+	const bool fuse = shadows && !(sv.num_spheres > 0 && sv.num_tris == 0);
+	if (shadows) RT_CHECK(ctx->d_occ.reserve((size_t)off[bounces] * 4));
+	auto shadow_launch = [&](const NodeGeo* geo, int n, const int* n_ptr, int lo, int hi, unsigned int* occl,
+	                         const int* q_count) -> int {
+		FusedQueue fq{};
+		unsigned long long* cen = rt_census_ptr(ctx, 1);
+		if (q_count) {
+			fq.org = q_org; fq.dir = q_dir; fq.count_ptr = q_count; fq.capacity = n;
+			fq.hits = ctx->d_hits.as<Hit>(); fq.census = rt_census_ptr(ctx, 0);
+		}
+		if (hi <= lo && !q_count) return RT_HIP_OK;
+		const size_t lds = rt_trace_lds(sv, TRACE_BLOCK);
+		const int blocks = rt_trace_blocks(ctx, std::max<int64_t>((int64_t)n * (hi - lo), n), TRACE_BLOCK);
+		RT_CHECK(rt_begin_trace_timing(ctx));
+		if (cen)
+			hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(TRACE_BLOCK), lds, st, sv, geo, n, n_ptr, lo, hi,
+			                   ctx->cfg.shadow_t_max, occl, cen, fq);
+		else
+			hipLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(TRACE_BLOCK), lds, st, sv, geo, n, n_ptr, lo, hi,
+			                   ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr, fq);
+		RT_HIP_CHECK(hipGetLastError());
+		RT_CHECK(rt_end_trace_timing(ctx, 1));
+		return RT_HIP_OK;
+	};
+	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+	RT_HIP_CHECK(hipMemsetAsync(fc, 0, (size_t)nfc * 4, st));
+	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, n0, tile, rank,
+	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), fc + 0);
+	RT_HIP_CHECK(hipGetLastError());
+	for (int L = 0; L < bounces; ++L) {
+		const int n = (int)cap[L];
+		int* lc = fc + 8 + 8 * L;                      // this level's counters
+		const int* n_ptr = L == 0 ? nullptr : lc;      // level 0's count is known: n0
+		const bool recurse = (L + 1 < bounces);
+		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + off[L];
+		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
+		int* gate = ctx->d_gate.as<int>() + off[L];
+		unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
+		if (shadows) RT_HIP_CHECK(hipMemsetAsync(occl, 0, (size_t)n * 4, st));
+		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, n_ptr,
+		                   (const unsigned int*)nullptr, (const float*)nullptr, ctx->cfg.do_shadows, 1, recurse ? 1 : 0, gate,
+		                   q_org, q_dir, q_parent, lc + 1);
+		RT_HIP_CHECK(hipGetLastError());
+		const int nl = sv.num_lights, nl_a = (recurse && fuse) ? nl / 2 : nl;
+		if (!recurse) {
+			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr));
+			break;
+		}
+		NodeGeo* child_geo = ctx->d_nodes_a.as<NodeGeo>() + off[L + 1];
+		int* child_count = lc + 8;                     // = level L+1's node count
+		const int child_cap = (int)cap[L + 1];
+		if (fuse) {
+			RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl_a, occl, lc + 1));
+			hipLaunchKernelGGL(k_resolve, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, ctx->d_hits.as<Hit>(), n, lc + 1, d_hi);
+		} else {
+			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr));
+			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 1));
+		}
+		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, n, lc + 1, 0,
+		                   gate, child_geo, child_count, child_cap, fc + 1);
+		// refraction, gated after the reflection hits are known (Q9)
+		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, n_ptr, gate, q_org, q_dir,
+		                   q_parent, lc + 2);
+		RT_HIP_CHECK(hipGetLastError());
+		if (fuse) {
+			RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2));
+			hipLaunchKernelGGL(k_resolve, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, ctx->d_hits.as<Hit>(), n, lc + 2, d_hi);
+		} else {
+			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
+		}
+		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, n, lc + 2, 1,
+		                   gate, child_geo, child_count, child_cap, fc + 1);
+		RT_HIP_CHECK(hipGetLastError());
+	}
+	for (int L = bounces - 1; L >= 0; --L) {
+		const int* n_ptr = L == 0 ? nullptr : fc + 8 + 8 * L;
+		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + off[L];
+		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
+		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + off[L - 1] : nullptr;
+		const unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
+		hipLaunchKernelGGL(k_combine, dim3(nblocks((int)cap[L], BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, (int)cap[L], n_ptr, L,
+		                   pshade, d_rgba, (float*)nullptr, 1, occl);
+		RT_HIP_CHECK(hipGetLastError());
+	}
+	int* h_fc = (int*)ctx->h_small;  // 4 KiB pinned; nfc <= 80 ints
+	RT_HIP_CHECK(hipMemcpyAsync(h_fc, fc, (size_t)nfc * 4, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+	RT_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+	if (h_fc[1]) {
+		*overflowed = true;
+		ctx->trace_events_used = 0;  // the frame is rendered again; drop this attempt's timings
+		return RT_HIP_OK;
+	}
+	int64_t rays_any = 0, rays_closest = 0;
+	int levels = 0;
+	for (int L = 0; L < bounces; ++L) {
+		const int nL = L == 0 ? n0 : h_fc[8 + 8 * L];
+		if (nL == 0) break;
+		levels = L + 1;
+		if (shadows) rays_any += (int64_t)(L == 0 ? h_fc[0] : nL) * sv.num_lights;
+		rays_closest += (int64_t)h_fc[8 + 8 * L + 1] + h_fc[8 + 8 * L + 2];
+	}
+	ctx->stats.rays_any += rays_any;
+	ctx->stats.rays_closest += rays_closest;
+	float ms = 0;
+	RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+	ctx->stats.frame_ms += ms;
+	ctx->stats.frames += 1;
+	ctx->last_frame_rays = rays_any + rays_closest;
+	ctx->last_count = levels;
+	RT_CHECK(rt_collect_timing(ctx));
+	return RT_HIP_OK;
+}
+
+static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
+                             int rank, int nranks, uint8_t* d_rgba);
+
 int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
                     int rank, int nranks, uint8_t* d_rgba)
+{
+	ctx->last_frame_rays = 0;
+	if (w <= 0 || h <= 0 || ctx->cfg.bounces <= 0) return RT_HIP_OK;
+	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 28) { rt_set_error("frame larger than 2^28 texels"); return RT_HIP_ERR_LIMIT; }
+	if (ctx->cfg.bounces > 8) { rt_set_error("bounces > 8 not supported"); return RT_HIP_ERR_LIMIT; }
+	if ((int)ctx->lights.size() > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
+	// The photon gather takes its point count on the host, so photon-mapped frames stay on the
+	// synchronous path.  RT_HIP_FRAME_SYNC=1 forces it (tests compare the two).
+	const char* e = getenv("RT_HIP_FRAME_SYNC");
+	const int force_sync = e ? atoi(e) : 0;
+	if (!ctx->cfg.use_photon_map && !force_sync) {
+		bool overflowed = false, declined = false;
+		RT_CHECK(render_frame_async(ctx, d_pos_rgb, d_nrm_rgba, w, h, tile, rank, nranks, d_rgba, &overflowed, &declined));
+		if (!overflowed && !declined) return RT_HIP_OK;
+	}
+	return render_frame_sync(ctx, d_pos_rgb, d_nrm_rgba, w, h, tile, rank, nranks, d_rgba);
+}
+
+static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
+                             int rank, int nranks, uint8_t* d_rgba)
 {
 	hipStream_t st = ctx->stream;
 	SceneView sv = rt_scene_view(ctx);
 	const int bounces = ctx->cfg.bounces;
-	ctx->last_frame_rays = 0;
-	if (w <= 0 || h <= 0 || bounces <= 0) return RT_HIP_OK;
-	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 28) { rt_set_error("frame larger than 2^28 texels"); return RT_HIP_ERR_LIMIT; }
 	const int npix = tile8_count(w, h);  // level-0 nodes: the frame padded to whole 8x8 tiles
-	if (bounces > 8) { rt_set_error("bounces > 8 not supported"); return RT_HIP_ERR_LIMIT; }
-	if (sv.num_lights > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
 	const bool spheres = sv.num_spheres > 0 && sv.num_tris == 0;
 
 	// level arrays: level L can hold at most 2^L * npix nodes, but only what was spawned is used;
@@ -895,10 +1143,11 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 			unsigned long long* cen = rt_census_ptr(ctx, 1);
 			if (cen)
 				hipLaunchKernelGGL(k_shadow<true>, dim3(rt_trace_blocks(ctx, total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
-				                   ctx->cfg.shadow_t_max, occl, cen);
+				                   (const int*)nullptr, 0, sv.num_lights, ctx->cfg.shadow_t_max, occl, cen, FusedQueue{});
 			else
 				hipLaunchKernelGGL(k_shadow<false>, dim3(rt_trace_blocks(ctx, total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
-				                   ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr);
+				                   (const int*)nullptr, 0, sv.num_lights, ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr,
+				                   FusedQueue{});
 			RT_HIP_CHECK(hipGetLastError());
 			RT_CHECK(rt_end_trace_timing(ctx, 1));
 			int64_t issued = (int64_t)(L == 0 ? active0 : n) * sv.num_lights;  // only active nodes trace
@@ -916,8 +1165,8 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 		HitInfo* d_hi = ctx->d_records.as<HitInfo>();
 
 		RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 16, st));
-		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, occl,
-		                   photon_rgb, ctx->cfg.do_shadows, recurse ? 1 : 0, gate, q_org, q_dir, q_parent, qcount);
+		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n,
+		                   (const int*)nullptr, occl, photon_rgb, ctx->cfg.do_shadows, 0, recurse ? 1 : 0, gate, q_org, q_dir, q_parent, qcount);
 		RT_HIP_CHECK(hipGetLastError());
 		if (!recurse) break;
 
@@ -934,14 +1183,14 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 		if (nq > 0) {
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
 			rays += nq;
-			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, nq, 0,
-			                   gate, child_geo, qcount + 1);
+			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, nq,
+			                   (const int*)nullptr, 0, gate, child_geo, qcount + 1, 0x7fffffff, qcount + 2);
 			RT_HIP_CHECK(hipGetLastError());
 		}
 		// refraction, gated after the reflection hits are known (Q9)
 		RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 4, st));
-		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, gate, q_org, q_dir,
-		                   q_parent, qcount);
+		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, (const int*)nullptr, gate,
+		                   q_org, q_dir, q_parent, qcount);
 		RT_HIP_CHECK(hipGetLastError());
 		RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
 		RT_HIP_CHECK(hipStreamSynchronize(st));
@@ -949,8 +1198,8 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 		if (nq > 0) {
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
 			rays += nq;
-			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, nq, 1,
-			                   gate, child_geo, qcount + 1);
+			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, nq,
+			                   (const int*)nullptr, 1, gate, child_geo, qcount + 1, 0x7fffffff, qcount + 2);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
 			RT_HIP_CHECK(hipStreamSynchronize(st));
@@ -967,8 +1216,8 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + geo_off[L];
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + geo_off[L];
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + geo_off[L - 1] : nullptr;
-		hipLaunchKernelGGL(k_combine, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, L, pshade, d_rgba,
-		                   (float*)nullptr);
+		hipLaunchKernelGGL(k_combine, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, (const int*)nullptr, L,
+		                   pshade, d_rgba, (float*)nullptr, 0, (const unsigned int*)nullptr);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));

@@ -398,7 +398,8 @@ static int build_ploc(rt_hip_ctx* ctx, int n, float pad, const uint32_t* order, 
                       int* node_parent, int* leaf_parent, BoxSlot* slots)
 {
 	hipStream_t st = ctx->stream;
-	int r = 16;
+	// search radius: 8 measured best on atrium-262k (nodes/ray 28.1; 16: 30.3, 32: 28.5, 64: 30.7; LBVH 31.4)
+	int r = 8;
 	if (const char* e = getenv("RT_HIP_PLOC_RADIUS")) r = std::min(PR_MAX, std::max(1, atoi(e)));
 	const int nb0 = (n + PB - 1) / PB;
 	// scratch: 2 cluster lists, 2 cluster box lists, nn, flag, block counts, totals

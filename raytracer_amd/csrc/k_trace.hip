@@ -20,9 +20,10 @@ constexpr int BVH_BLOCK = 128;
 template <int MODE>  // 0 closest, 1 any (intersect tests), 2 AccelArray::occlude
 __global__ __launch_bounds__(BLOCK) void k_brute(const TriIsect* __restrict__ tris, int num_tris,
                                                  const float* __restrict__ org, const float* __restrict__ dir,
-                                                 int n, TraceParams tp, Hit* __restrict__ hits,
-                                                 uint8_t* __restrict__ occ)
+                                                 int n, const int* __restrict__ n_ptr, TraceParams tp,
+                                                 Hit* __restrict__ hits, uint8_t* __restrict__ occ)
 {
+	if (n_ptr) { int m = *n_ptr; n = m < n ? m : n; }
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
 	f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(BLOCK) void k_brute(const TriIsect* __restrict__ tr
 // ---- LBVH traversal ---------------------------------------------------------------------------
 template <bool ANY, bool CENSUS>
 __global__ __launch_bounds__(BVH_BLOCK) void k_bvh(SceneView sv, const float* __restrict__ org,
-                                                   const float* __restrict__ dir, int n, Hit* __restrict__ hits,
+                                                   const float* __restrict__ dir, int n, const int* __restrict__ n_ptr,
+                                                   Hit* __restrict__ hits,
                                                    uint8_t* __restrict__ occ, uint32_t* __restrict__ nv,
                                                    uint32_t* __restrict__ nt, unsigned long long* census)
 {
@@ -59,6 +61,7 @@ __global__ __launch_bounds__(BVH_BLOCK) void k_bvh(SceneView sv, const float* __
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
 	int* spill = sv.spill + (blockIdx.x * BVH_BLOCK + threadIdx.x);
+	if (n_ptr) { int m = *n_ptr; n = m < n ? m : n; }  // count on the device, n = capacity (sync-free frame path)
 	uint32_t cn = 0, ct = 0, rays = 0;
 	grid_for_each(sv, n, [&](int64_t i) {
 		f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
@@ -113,7 +116,7 @@ inline int nblocks(int n, int b) { return (n + b - 1) / b; }
 
 }  // namespace
 
-int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, Hit* d_hits)
+int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, Hit* d_hits, const int* d_count)
 {
 	if (n <= 0) return RT_HIP_OK;
 	SceneView sv = rt_scene_view(ctx);
@@ -122,24 +125,25 @@ int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, i
 	if (sv.use_bvh && cen) {
 		size_t lds = rt_trace_lds(sv, BVH_BLOCK);
 		hipLaunchKernelGGL((k_bvh<false, true>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cen);
+		                   d_org, d_dir, n, d_count, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, cen);
 	} else if (sv.use_bvh) {
 		size_t lds = rt_trace_lds(sv, BVH_BLOCK);
 		hipLaunchKernelGGL((k_bvh<false, false>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+		                   d_org, d_dir, n, d_count, d_hits, (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
 		                   (unsigned long long*)nullptr);
 	} else {
 		hipLaunchKernelGGL((k_brute<0>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv.tris, sv.num_tris,
-		                   d_org, d_dir, n, sv.tp, d_hits, (uint8_t*)nullptr);
+		                   d_org, d_dir, n, d_count, sv.tp, d_hits, (uint8_t*)nullptr);
 	}
 	RT_HIP_CHECK(hipGetLastError());
 	RT_CHECK(rt_end_trace_timing(ctx, 0));
-	ctx->stats.rays_closest += n;
+	if (!d_count) ctx->stats.rays_closest += n;  // with a device-side count the caller accounts for the rays
 	return RT_HIP_OK;
 }
 
 int rt_launch_any(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ)
 {
+	const int* d_count = nullptr;
 	if (n <= 0) return RT_HIP_OK;
 	SceneView sv = rt_scene_view(ctx);
 	RT_CHECK(rt_begin_trace_timing(ctx));
@@ -147,15 +151,15 @@ int rt_launch_any(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n
 	if (sv.use_bvh && cen) {
 		size_t lds = rt_trace_lds(sv, BVH_BLOCK);
 		hipLaunchKernelGGL((k_bvh<true, true>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr, cen);
+		                   d_org, d_dir, n, d_count, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr, cen);
 	} else if (sv.use_bvh) {
 		size_t lds = rt_trace_lds(sv, BVH_BLOCK);
 		hipLaunchKernelGGL((k_bvh<true, false>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr,
+		                   d_org, d_dir, n, d_count, (Hit*)nullptr, d_occ, (uint32_t*)nullptr, (uint32_t*)nullptr,
 		                   (unsigned long long*)nullptr);
 	} else {
 		hipLaunchKernelGGL((k_brute<1>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv.tris, sv.num_tris,
-		                   d_org, d_dir, n, sv.tp, (Hit*)nullptr, d_occ);
+		                   d_org, d_dir, n, (const int*)nullptr, sv.tp, (Hit*)nullptr, d_occ);
 	}
 	RT_HIP_CHECK(hipGetLastError());
 	RT_CHECK(rt_end_trace_timing(ctx, 1));
@@ -171,7 +175,7 @@ int rt_launch_occlude_ref(rt_hip_ctx* ctx, const float* d_org, const float* d_di
 	if (n <= 0) return RT_HIP_OK;
 	SceneView sv = rt_scene_view(ctx);
 	hipLaunchKernelGGL((k_brute<2>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv.tris, sv.num_tris,
-	                   d_org, d_dir, n, sv.tp, (Hit*)nullptr, d_occ);
+	                   d_org, d_dir, n, (const int*)nullptr, sv.tp, (Hit*)nullptr, d_occ);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }
@@ -185,13 +189,14 @@ int rt_launch_census(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, in
 		rt_set_error("census needs the LBVH (accel = brute force)");
 		return RT_HIP_ERR_STATE;
 	}
+	const int* d_count = nullptr;
 	size_t lds = rt_trace_lds(sv, BVH_BLOCK);
 	if (any_hit)
 		hipLaunchKernelGGL((k_bvh<true, true>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt, (unsigned long long*)nullptr);
+		                   d_org, d_dir, n, d_count, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt, (unsigned long long*)nullptr);
 	else
 		hipLaunchKernelGGL((k_bvh<false, true>), dim3(rt_trace_blocks(ctx, n, BVH_BLOCK)), dim3(BVH_BLOCK), lds, ctx->stream, sv,
-		                   d_org, d_dir, n, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt, (unsigned long long*)nullptr);
+		                   d_org, d_dir, n, d_count, (Hit*)nullptr, (uint8_t*)nullptr, d_nv, d_nt, (unsigned long long*)nullptr);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }

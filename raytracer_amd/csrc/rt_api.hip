@@ -138,8 +138,9 @@ SceneView rt_scene_view(const rt_hip_ctx* ctx)
 }
 
 // ---- kernel timing (profile mode) -------------------------------------------------------------
-int rt_begin_trace_timing(rt_hip_ctx* ctx)
+int rt_begin_trace_timing(rt_hip_ctx* ctx, hipStream_t st)
 {
+	if (!st) st = ctx->stream;
 	if (!ctx->cfg.profile) return RT_HIP_OK;
 	if (ctx->trace_events_used == ctx->trace_events.size()) {
 		hipEvent_t a, b;
@@ -148,15 +149,16 @@ int rt_begin_trace_timing(rt_hip_ctx* ctx)
 		ctx->trace_events.push_back(std::make_pair(a, b));
 		ctx->trace_event_class.push_back(0);
 	}
-	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].first, ctx->stream));
+	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].first, st));
 	return RT_HIP_OK;
 }
 
-int rt_end_trace_timing(rt_hip_ctx* ctx, int cls)
+int rt_end_trace_timing(rt_hip_ctx* ctx, int cls, hipStream_t st)
 {
+	if (!st) st = ctx->stream;
 	if (cls) ctx->stats.any_launches += 1; else ctx->stats.closest_launches += 1;
 	if (!ctx->cfg.profile) return RT_HIP_OK;
-	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].second, ctx->stream));
+	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].second, st));
 	ctx->trace_event_class[ctx->trace_events_used] = cls;
 	++ctx->trace_events_used;
 	return RT_HIP_OK;
@@ -167,7 +169,7 @@ unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls)
 	if (!ctx->cfg.census) return nullptr;
 	if (!ctx->d_census.p) {
 		if (ctx->d_census.reserve(64) != RT_HIP_OK) return nullptr;
-		if (hipMemsetAsync(ctx->d_census.p, 0, 64, ctx->stream) != hipSuccess) return nullptr;
+		if (hipMemset(ctx->d_census.p, 0, 64) != hipSuccess) return nullptr;  // synchronous: two streams add to it
 	}
 	return ctx->d_census.as<unsigned long long>() + (cls ? 3 : 0);
 }

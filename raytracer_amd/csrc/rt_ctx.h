@@ -129,8 +129,8 @@ constexpr int RT_TRACE_OVERSUB = 4;
 // total (the spill stack has exactly that many columns).
 int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block);
 size_t rt_trace_lds(const SceneView& sv, int block);  // RT_HIP_EXTRA_LDS (bytes): occupancy experiments only
-int rt_begin_trace_timing(rt_hip_ctx* ctx);
-int rt_end_trace_timing(rt_hip_ctx* ctx, int cls);
+int rt_begin_trace_timing(rt_hip_ctx* ctx, hipStream_t st = nullptr);  // nullptr: ctx->stream
+int rt_end_trace_timing(rt_hip_ctx* ctx, int cls, hipStream_t st = nullptr);
 unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls);  // nullptr unless cfg.census
 int rt_collect_timing(rt_hip_ctx* ctx);
 int rt_ensure_pinned(void** p, size_t* cap, size_t bytes);
@@ -142,7 +142,9 @@ int rt_build_geometry(rt_hip_ctx* ctx);  // soup + (optional) LBVH, all on ctx->
 int rt_build_lbvh(rt_hip_ctx* ctx);
 
 // ---- k_trace.hip ---------------------------------------------------------------------------------
-int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, Hit* d_hits);
+// d_count != nullptr: n is the capacity, the ray count is read on the device (brute force ignores it: BVH only)
+int rt_launch_closest(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, Hit* d_hits,
+                      const int* d_count = nullptr);
 int rt_launch_any(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ);
 int rt_launch_occlude_ref(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, uint8_t* d_occ);
 int rt_launch_census(rt_hip_ctx* ctx, const float* d_org, const float* d_dir, int n, int any_hit, uint32_t* d_nv,

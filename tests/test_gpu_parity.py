@@ -301,12 +301,15 @@ def _frame_inputs(orc, sc, w, h):
                          ids=["cornell-brute", "cornell-lbvh", "atrium2k-lbvh"])
 @pytest.mark.parametrize("shadows,bounces,stmax", [(0, 2, 0.0), (1, 2, 0.0), (1, 3, 0.0), (1, 2, 1.0)],
                          ids=["noshadow-b2", "shadow-b2", "shadow-b3", "shadowfix-b2"])
-def test_render_frame(rt, oracle_cls, scene_fn, accel, shadows, bounces, stmax):
+@pytest.mark.parametrize("path", ["async", "sync"])
+def test_render_frame(rt, oracle_cls, scene_fn, accel, shadows, bounces, stmax, path, monkeypatch):
     """Full frame (Gen-1 shade() at G-buffer texels) vs the oracle; tolerance = north_star's
-    max-abs 1/255 per channel, and in practice the images are identical."""
+    max-abs 1/255 per channel, and in practice the images are identical.  Both frame drivers: the
+    default one keeps every count on the device, RT_HIP_FRAME_SYNC=1 sizes each level on the host."""
+    monkeypatch.setenv("RT_HIP_FRAME_SYNC", "1" if path == "sync" else "0")
     sc = scene_fn()
     orc = oracle_cls(sc)
-    w, h = 96, 72
+    w, h = 100, 75                          # not multiples of 8: partial 8x8 tiles at the right and top edges
     nr, po, mid, nrm = _frame_inputs(orc, sc, w, h)
     exp_rgba, _, exp_rays = orc.render_texels(po, nrm, mid, bounces=bounces, do_shadows=shadows, shadow_t_max=stmax)
     g = rt.RtHip(sc, semantics="array", accel=accel, bounces=bounces, do_shadows=shadows, shadow_t_max=stmax)
