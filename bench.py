@@ -36,6 +36,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 78.6  # per-lane v_fma_f32 rate (157 TFLOP/s needs packed/dual-issue FP32 throughout)
+
+
+def pmc_traffic(workload, shadow_mode, accel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes of this
+    same command (profiles/r1_pmc_traffic.json, made by scripts/profile_round.sh); None for any other
+    configuration -- counters cannot be read from inside the process being measured."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not (workload == "atrium-262k-1080p" and shadow_mode == "corrected" and accel == "ploc" and os.path.exists(path)):
+        return None
+    with open(path) as f:
+        return float(json.load(f)["traffic_bytes_per_launch"])
 
 
 def parse_args():
@@ -195,7 +207,15 @@ def main():
         bpr, nodes_dom, tris_dom = bytes_per_clo, nodes_clo, tris_clo
     achieved = (rays_per_launch * bpr) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic(args.workload, args.shadow_mode, args.accel) if (world == 1 and args.photons == 0) else None,
+                "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_traffic.json); the "
+                                "algorithmic bytes are served by L1/L2/Infinity Cache, so achieved > peak is expected and HBM "
+                                "is not the binding limit: see `valu`",
+                "valu": {"unit": "TFLOP/s", "flop_per_ray": round(48.0 * nodes_dom + 45.0 * tris_dom, 1),
+                         "achieved": round(rays_per_launch * (48.0 * nodes_dom + 45.0 * tris_dom) / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0,
+                         "peak": VALU_PEAK_TFLOPS,
+                         "frac": round(rays_per_launch * (48.0 * nodes_dom + 45.0 * tris_dom) / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4) if avg_ms > 0 else 0.0},
                 "kernel": dominant, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": round(rays_per_launch, 1),
                 "nodes_per_ray": round(nodes_dom, 2), "tris_per_ray": round(tris_dom, 2),
                 "bytes_per_ray": round(bpr, 1),

@@ -96,6 +96,9 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 			} else {
 				const TriIsect* tp = sv.tris + (~cur);
 				float4 a = tp->a, b = tp->b, c = tp->c;
+				// keep the three loads together: left alone, the compiler sinks the load of `a` below
+				// the det test and the leaf visit pays two memory round trips instead of one
+				asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
 				if (CENSUS) ++cnt_tris;
 				f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
 				if (ANY) {
