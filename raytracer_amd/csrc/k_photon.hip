@@ -196,21 +196,19 @@ struct GatherConst {
 	float alpha, beta, e, gauss_denom, two_pi;
 };
 
+// Visit every photon whose grid cell intersects the cube of half-width rho around P (a superset of
+// the sphere of radius rho).  Cells along x are contiguous in the sorted array: one span per (y,z).
 template <typename F>
 __device__ __forceinline__ void for_each_neighbour(const GridDesc& gd, const uint32_t* __restrict__ cell_start,
-                                                   const float4* __restrict__ pos, f3 P, int range, F f)
+                                                   const float4* __restrict__ pos, f3 P, float rho, F f)
 {
-	int cx = (int)floorf((P.x - gd.mn[0]) * gd.inv_cell);
-	int cy = (int)floorf((P.y - gd.mn[1]) * gd.inv_cell);
-	int cz = (int)floorf((P.z - gd.mn[2]) * gd.inv_cell);
-	int x0 = max(cx - range, 0), x1 = min(cx + range, gd.dim[0] - 1);
-	int y0 = max(cy - range, 0), y1 = min(cy + range, gd.dim[1] - 1);
-	int z0 = max(cz - range, 0), z1 = min(cz + range, gd.dim[2] - 1);
+	rho = rho * 1.0001f + 1e-30f;  // the cell of a photon at distance <= rho must not fall outside by rounding
+	int x0 = cell_coord(P.x - rho, gd.mn[0], gd.inv_cell, gd.dim[0]), x1 = cell_coord(P.x + rho, gd.mn[0], gd.inv_cell, gd.dim[0]);
+	int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
+	int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
 	for (int z = z0; z <= z1; ++z)
 		for (int y = y0; y <= y1; ++y) {
-			// cells along x are contiguous in the sorted array: one span per (y, z) row
 			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
-			if (x0 > x1) continue;
 			uint32_t s0 = cell_start[row + x0], s1 = cell_start[row + x1 + 1];
 			for (uint32_t s = s0; s < s1; ++s) {
 				float4 q = pos[s];
@@ -220,49 +218,141 @@ __device__ __forceinline__ void for_each_neighbour(const GridDesc& gd, const uin
 		}
 }
 
-__global__ __launch_bounds__(256) void k_photon_gather(GridDesc gd, const uint32_t* __restrict__ cell_start,
-                                                       const float4* __restrict__ pos,
-                                                       const float4* __restrict__ payload, int64_t nph,
-                                                       const float* __restrict__ qpos, const float* __restrict__ qnrm,
-                                                       int npts, int count, float radius, int range, GatherConst gc,
-                                                       float* __restrict__ rgb)
+// PhotonMap::radiance_estimate (rt_photon_map.cpp:149-208), one lane per shading point.
+//   pass 1   all photons within `radius`: their number, max_dist2 over ALL of them (:159-169), and a
+//            64-bin histogram of the squared distance over [0, r^2)
+//   select   the `count`-th smallest squared distance tau by histogram refinement: the bin holding the
+//            count-th is split into 64 again (at most SEL_LEVELS times), each time reading only the
+//            cells that can hold a photon below the bin's upper edge; when at most SEL_LIST
+//            candidates remain they are ranked in LDS.  Ties at tau are taken in traversal order.
+//   pass 3   the weighted sum over the selected photons (:178-197)
+// Histograms and candidate lists are per lane, laid out [slot][lane] in LDS (conflict free).
+constexpr int GBLOCK = 128;
+constexpr int SEL_BINS = 64;
+constexpr int SEL_LEVELS = 4;
+constexpr int SEL_LIST = 64;
+
+struct SelLevel {
+	float lo, scale;  // bin(l2) = clamp(int((l2 - lo) * scale), 0, 63)
+	int bin;          // the bin the search descended into
+};
+
+__device__ __forceinline__ int sel_bin(float l2, float lo, float scale)
 {
-	int i = blockIdx.x * 256 + threadIdx.x;
+	int b = (int)((l2 - lo) * scale);
+	return min(max(b, 0), SEL_BINS - 1);
+}
+
+__global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uint32_t* __restrict__ cell_start,
+                                                          const float4* __restrict__ pos,
+                                                          const float4* __restrict__ payload, int64_t nph,
+                                                          const float* __restrict__ qpos, const float* __restrict__ qnrm,
+                                                          int npts, int count, float radius, GatherConst gc,
+                                                          float* __restrict__ rgb)
+{
+	__shared__ uint32_t s_hist[SEL_BINS * GBLOCK];  // doubles as the candidate list (SEL_LIST <= SEL_BINS)
+	uint32_t* hist = s_hist + threadIdx.x;
+	int i = blockIdx.x * GBLOCK + threadIdx.x;
 	if (i >= npts) return;
 	f3 P = ld3(qpos + 3 * (size_t)i), N = ld3(qnrm + 3 * (size_t)i);
 	const float r2 = radius * radius;
-	// pass 1: candidates and max_dist2 over ALL of them (:159-169)
+	SelLevel lv[SEL_LEVELS];
+	int nlv = 0;
+	// is l2 among the candidates of refinement level `upto`?
+	auto in_levels = [&](float l2, int upto) {
+		bool ok = l2 < r2;
+		for (int k = 0; k < SEL_LEVELS; ++k)
+			if (k < upto) ok = ok && sel_bin(l2, lv[k].lo, lv[k].scale) == lv[k].bin;
+		return ok;
+	};
+	// pass 1
 	int nc = 0;
 	float max_dist2 = 0.0f;
+	lv[0].lo = 0.0f; lv[0].scale = (float)SEL_BINS / r2; lv[0].bin = 0;
+	for (int b = 0; b < SEL_BINS; ++b) hist[b * GBLOCK] = 0u;
 	if (nph > 0)
-		for_each_neighbour(gd, cell_start, pos, P, range, [&](uint32_t, float l2) {
-			if (l2 < r2) { ++nc; if (l2 > max_dist2) max_dist2 = l2; }
+		for_each_neighbour(gd, cell_start, pos, P, radius, [&](uint32_t, float l2) {
+			if (l2 < r2) {
+				++nc;
+				if (l2 > max_dist2) max_dist2 = l2;
+				++hist[sel_bin(l2, lv[0].lo, lv[0].scale) * GBLOCK];
+			}
 		});
-	// threshold of the `count` nearest: smallest bit pattern tau with #(l2 <= tau) >= count
-	uint32_t tau = 0xFFFFFFFFu;
+	uint32_t tau = 0xFFFFFFFFu;  // bit pattern of the count-th smallest l2 (all candidates if nc <= count)
 	int take_equal = 0x7fffffff;
+	float rho_sel = radius;      // radius that certainly contains everything <= tau
 	if (nc > count) {
-		uint32_t lo = 0u, hi = __float_as_uint(r2);  // l2 < r2, so bits(l2) < bits(r2)
-		while (lo < hi) {
-			uint32_t mid = lo + ((hi - lo) >> 1);
-			int c = 0;
-			for_each_neighbour(gd, cell_start, pos, P, range, [&](uint32_t, float l2) {
-				if (l2 < r2 && __float_as_uint(l2) <= mid) ++c;
+		int need = count;        // rank (1-based) of the wanted element among the current candidates
+		int pop = nc;            // current candidates
+		float hi_edge = r2;
+		for (;;) {
+			// descend into the bin that holds the need-th candidate
+			int b = 0, cum = 0;
+			for (; b < SEL_BINS - 1; ++b) {
+				int h = (int)hist[b * GBLOCK];
+				if (cum + h >= need) break;
+				cum += h;
+			}
+			need -= cum;
+			pop = (int)hist[b * GBLOCK];
+			const float width = 1.0f / lv[nlv].scale;
+			const float lo_edge = lv[nlv].lo + (float)b * width;
+			// upper bound of the squared distances in this bin, with slack for the rounding of the bin
+			// function; the top bin also holds what the clamp folded into it: keep the parent's bound
+			if (b < SEL_BINS - 1) hi_edge = fminf(hi_edge, lo_edge + width * 1.001f + fabsf(lo_edge) * 4e-6f);
+			lv[nlv].bin = b;
+			++nlv;
+			rho_sel = fminf(radius, rt_sqrtf(hi_edge) * 1.001f);
+			if (pop <= SEL_LIST || nlv == SEL_LEVELS || !(width > 0.0f)) break;
+			lv[nlv].lo = lo_edge; lv[nlv].scale = (float)SEL_BINS / width; lv[nlv].bin = 0;
+			for (int k = 0; k < SEL_BINS; ++k) hist[k * GBLOCK] = 0u;
+			const int upto = nlv;
+			for_each_neighbour(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2) {
+				if (in_levels(l2, upto)) ++hist[sel_bin(l2, lv[upto].lo, lv[upto].scale) * GBLOCK];
 			});
-			if (c >= count) hi = mid; else lo = mid + 1;
 		}
-		tau = lo;
-		int less = 0;
-		for_each_neighbour(gd, cell_start, pos, P, range, [&](uint32_t, float l2) {
-			if (l2 < r2 && __float_as_uint(l2) < tau) ++less;
-		});
-		take_equal = count - less;
+		if (pop <= SEL_LIST) {
+			// rank the remaining candidates in LDS
+			int m = 0;
+			const int upto = nlv;
+			for_each_neighbour(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2) {
+				if (in_levels(l2, upto) && m < SEL_LIST) { hist[m * GBLOCK] = __float_as_uint(l2); ++m; }
+			});
+			for (int a = 0; a < m; ++a) {
+				const uint32_t v = hist[a * GBLOCK];
+				int lt = 0, le = 0;
+				for (int c = 0; c < m; ++c) {
+					const uint32_t x = hist[c * GBLOCK];
+					lt += x < v; le += x <= v;
+				}
+				if (lt < need && need <= le) { tau = v; take_equal = need - lt; break; }
+			}
+		} else {
+			// more than SEL_LIST candidates inside one bin of the last level (heavily duplicated
+			// distances): bisect on the bit pattern among them
+			const int upto = nlv;
+			uint32_t lo = 0u, hi = __float_as_uint(r2);
+			while (lo < hi) {
+				uint32_t mid = lo + ((hi - lo) >> 1);
+				int c = 0;
+				for_each_neighbour(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2) {
+					if (in_levels(l2, upto) && __float_as_uint(l2) <= mid) ++c;
+				});
+				if (c >= need) hi = mid; else lo = mid + 1;
+			}
+			tau = lo;
+			int less = 0;
+			for_each_neighbour(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2) {
+				if (in_levels(l2, upto) && __float_as_uint(l2) < tau) ++less;
+			});
+			take_equal = need - less;
+		}
 	}
 	// pass 3: weighted sum over the selected photons (:178-197)
 	f3 result = mk3(0, 0, 0);
 	if (nc > 0) {
 		const float denom2 = 2.0f * max_dist2;
-		for_each_neighbour(gd, cell_start, pos, P, range, [&](uint32_t s, float l2) {
+		for_each_neighbour(gd, cell_start, pos, P, rho_sel, [&](uint32_t s, float l2) {
 			if (!(l2 < r2)) return;
 			uint32_t b = __float_as_uint(l2);
 			bool sel = b < tau;
@@ -346,8 +436,9 @@ int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	float mn[3], mx[3];
 	for (int k = 0; k < 3; ++k) { mn[k] = ord2f(ob[k]); mx[k] = ord2f(ob[3 + k]); }
-	// cell = photon_radius, enlarged until the grid has at most 2^22 cells
-	float cell = ctx->cfg.photon_radius > 0.0f ? ctx->cfg.photon_radius : 1.0f;
+	// cell = photon_radius / 2 (the selection passes of the gather read only the cells under their
+	// current distance bound, so finer cells pay), enlarged until the grid has at most 2^22 cells
+	float cell = (ctx->cfg.photon_radius > 0.0f ? ctx->cfg.photon_radius : 1.0f) * 0.5f;
 	int dim[3];
 	for (;;) {
 		double cells = 1;
@@ -393,17 +484,15 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	GridDesc gd;
 	for (int k = 0; k < 3; ++k) { gd.mn[k] = ctx->photon_grid_min[k]; gd.dim[k] = ctx->num_photons ? ctx->photon_grid_dim[k] : 1; }
 	gd.cell = ctx->photon_cell; gd.inv_cell = 1.0f / ctx->photon_cell;
-	int range = (int)std::ceil(radius / ctx->photon_cell);
-	if (range < 1) range = 1;
 	// rt_photon_map.cpp:13-18, evaluated in float exactly as the reference's file-scope constants
 	const float ALPHA = 0.918, BETA = 1.953, PI = 3.141592653589793, E = 2.718281828459045;
 	GatherConst gc;
 	gc.alpha = ALPHA; gc.beta = BETA; gc.e = E;
 	gc.gauss_denom = 1 / (1 - powf(E, -BETA));
 	gc.two_pi = 2 * PI;
-	hipLaunchKernelGGL(k_photon_gather, dim3(nblocks(npts, 256)), dim3(256), 0, ctx->stream, gd,
+	hipLaunchKernelGGL(k_photon_gather, dim3(nblocks(npts, GBLOCK)), dim3(GBLOCK), 0, ctx->stream, gd,
 	                   ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(),
-	                   ctx->num_photons, d_pos, d_nrm, npts, count, radius, range, gc, d_rgb);
+	                   ctx->num_photons, d_pos, d_nrm, npts, count, radius, gc, d_rgb);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }
