@@ -16,7 +16,7 @@ disjoint RGBA8 tile images), inside the timed region.
 
 value = secondary rays issued by all ranks / wall time (barrier + synchronize on both sides, max
 over ranks).  roofline = the dominant kernel (the shadow any-hit traversal k_shadow) against HBM:
-algorithmic bytes = rays x (64 B x nodes/ray + 48 B x tris/ray + 48 B ray in/out), with nodes/ray
+algorithmic bytes = rays x (32 B x nodes/ray + 48 B x tris/ray + 48 B ray in/out), with nodes/ray
 and tris/ray counted on the device by a census pass over the identical frame.  cpu_baseline = the
 compiled reference's own RayTracer::processRays (oracle/_ref, kind "reference") or the oracle's
 restatement (kind "port") on a bounded sample of the same G-buffer, single thread as the
@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+NODE_BYTES = 32.0  # the traversal reads 32-byte quantised nodes (rt_dev.h: QNode); SURVEY 8d prices the float node at 64
 VALU_PEAK_TFLOPS = 78.6  # per-lane v_fma_f32 rate (157 TFLOP/s needs packed/dual-issue FP32 throughout)
 
 
@@ -183,8 +184,8 @@ def main():
     tris_any = cs["census_tris_any"] / max(cs["census_rays_any"], 1)
     nodes_clo = cs["census_nodes_closest"] / max(cs["census_rays_closest"], 1)
     tris_clo = cs["census_tris_closest"] / max(cs["census_rays_closest"], 1)
-    bytes_per_any = 64.0 * nodes_any + 48.0 * tris_any + 48.0
-    bytes_per_clo = 64.0 * nodes_clo + 48.0 * tris_clo + 48.0
+    bytes_per_any = NODE_BYTES * nodes_any + 48.0 * tris_any + 48.0
+    bytes_per_clo = NODE_BYTES * nodes_clo + 48.0 * tris_clo + 48.0
     fused = clo_launches == 0 and rays_clo > 0   # the frame driver folds the closest-hit queues into the shadow launches
     if fused:
         dominant = "k_shadow (shadow any-hit rays + the level's closest-hit queue in the same launch)"

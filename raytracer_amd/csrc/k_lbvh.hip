@@ -353,9 +353,28 @@ __global__ __launch_bounds__(PTAIL) void k_ploc_tail(const int* __restrict__ cl_
 	if (i == 0) node_parent[0] = -1;
 }
 
+// 16-bit grid coordinate of a plane, rounded outward; the comparison is made against the float the
+// traversal's arithmetic stands for (org + q * scale evaluated in float), so the quantised box
+// contains the float box.
+__device__ __forceinline__ uint32_t quant_lo(float v, float org, float scale)
+{
+	int q = (int)floorf((v - org) / scale);
+	q = min(max(q, 0), 65535);
+	while (q > 0 && __builtin_fmaf((float)q, scale, org) > v) --q;
+	return (uint32_t)q;
+}
+__device__ __forceinline__ uint32_t quant_hi(float v, float org, float scale)
+{
+	int q = (int)ceilf((v - org) / scale);
+	q = min(max(q, 0), 65535);
+	while (q < 65535 && __builtin_fmaf((float)q, scale, org) < v) ++q;
+	return (uint32_t)q;
+}
+
 __global__ __launch_bounds__(256) void k_emit_nodes(const BoxSlot* __restrict__ slots, int n,
                                                     const int* __restrict__ left, const int* __restrict__ right,
-                                                    const int* __restrict__ node_parent, BvhNode* __restrict__ nodes)
+                                                    const int* __restrict__ node_parent, BvhNode* __restrict__ nodes,
+                                                    QFrame qf, QNode* __restrict__ qnodes)
 {
 	int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n - 1) return;
@@ -368,6 +387,15 @@ __global__ __launch_bounds__(256) void k_emit_nodes(const BoxSlot* __restrict__ 
 	nd.q2 = make_float4(r->mn[2], r->mx[0], r->mx[1], r->mx[2]);
 	nd.left = lc; nd.right = rc; nd.parent = node_parent[i]; nd.pad = 0;
 	nodes[i] = nd;
+	uint32_t lq[6], rq[6];
+	for (int k = 0; k < 3; ++k) {
+		lq[k] = quant_lo(l->mn[k], qf.org[k], qf.scale[k]); lq[3 + k] = quant_hi(l->mx[k], qf.org[k], qf.scale[k]);
+		rq[k] = quant_lo(r->mn[k], qf.org[k], qf.scale[k]); rq[3 + k] = quant_hi(r->mx[k], qf.org[k], qf.scale[k]);
+	}
+	QNode qn;
+	qn.w0 = make_uint4(lq[0] | lq[1] << 16, lq[2] | lq[3] << 16, lq[4] | lq[5] << 16, rq[0] | rq[1] << 16);
+	qn.w1 = make_uint4(rq[2] | rq[3] << 16, rq[4] | rq[5] << 16, (uint32_t)lc, (uint32_t)rc);
+	qnodes[i] = qn;
 }
 
 __global__ __launch_bounds__(256) void k_permute_tris(const TriIsect* __restrict__ in, const uint32_t* __restrict__ order,
@@ -488,8 +516,15 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 		                   node_parent, leaf_parent, slots, arrive);
 	}
 	RT_CHECK(ctx->d_nodes.reserve((size_t)(n - 1) * sizeof(BvhNode)));
+	RT_CHECK(ctx->d_qnodes.reserve((size_t)(n - 1) * sizeof(QNode)));
+	// quantisation grid: the padded scene box, 65535 steps per axis (a flat axis gets a unit step)
+	for (int k = 0; k < 3; ++k) {
+		ctx->qframe.org[k] = ctx->bounds[k] - 2.0f * pad;
+		float e = (ctx->bounds[3 + k] + 2.0f * pad) - ctx->qframe.org[k];
+		ctx->qframe.scale[k] = e > 0.0f ? e / 65535.0f : 1.0f;
+	}
 	hipLaunchKernelGGL(k_emit_nodes, dim3(g), dim3(256), 0, st, slots, n, left, right, node_parent,
-	                   ctx->d_nodes.as<BvhNode>());
+	                   ctx->d_nodes.as<BvhNode>(), ctx->qframe, ctx->d_qnodes.as<QNode>());
 	// leaf-ordered intersection records (tri_isect currently holds original order)
 	RT_CHECK(ctx->d_in_a.reserve((size_t)n * sizeof(TriIsect)));
 	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_in_a.p, ctx->d_tri_isect.p, (size_t)n * sizeof(TriIsect), hipMemcpyDeviceToDevice, st));

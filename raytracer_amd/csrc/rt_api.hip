@@ -115,6 +115,8 @@ SceneView rt_scene_view(const rt_hip_ctx* ctx)
 {
 	SceneView sv;
 	sv.nodes = ctx->d_nodes.as<BvhNode>();
+	sv.qnodes = ctx->d_qnodes.as<QNode>();
+	sv.qframe = ctx->qframe;
 	sv.tris = ctx->d_tri_isect.as<TriIsect>();
 	sv.tri_pos = ctx->d_tri_pos.as<TriPos>();
 	sv.tri_attr = ctx->d_tri_attr.as<TriAttr>();
@@ -293,7 +295,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	(void)hipSetDevice(ctx->cfg.device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	DevBuf* bufs[] = {&ctx->d_verts, &ctx->d_normals, &ctx->d_texcoords, &ctx->d_faces, &ctx->d_mesh_of_tri, &ctx->d_mesh_xf,
-	                  &ctx->d_tri_pos, &ctx->d_tri_attr, &ctx->d_tri_isect, &ctx->d_tri_box, &ctx->d_nodes, &ctx->d_spheres,
+	                  &ctx->d_tri_pos, &ctx->d_tri_attr, &ctx->d_tri_isect, &ctx->d_tri_box, &ctx->d_nodes, &ctx->d_qnodes, &ctx->d_spheres,
 	                  &ctx->d_materials, &ctx->d_lights, &ctx->d_morton, &ctx->d_morton_tmp, &ctx->d_order, &ctx->d_order_tmp,
 	                  &ctx->d_hist, &ctx->d_flags, &ctx->d_parent_leaf, &ctx->d_bounds, &ctx->d_misc, &ctx->d_org, &ctx->d_dir,
 	                  &ctx->d_hits, &ctx->d_occ, &ctx->d_in_a, &ctx->d_in_b, &ctx->d_records, &ctx->d_offsets, &ctx->d_keys,

@@ -55,7 +55,9 @@ struct HostSphere {
 
 // Device scene views handed to kernels.
 struct SceneView {
-	const BvhNode* nodes;
+	const BvhNode* nodes;     // float nodes (build output, introspection)
+	const QNode* qnodes;      // 32-byte quantised nodes: what the traversal reads
+	QFrame qframe;            // their grid
 	const TriIsect* tris;     // leaf order
 	const TriPos* tri_pos;    // original id order
 	const TriAttr* tri_attr;  // original id order
@@ -94,10 +96,11 @@ struct rt_hip_ctx {
 
 	// geometry in HBM
 	DevBuf d_verts, d_normals, d_texcoords, d_faces, d_mesh_of_tri, d_mesh_xf;  // inputs of the soup kernel
-	DevBuf d_tri_pos, d_tri_attr, d_tri_isect, d_tri_box, d_nodes, d_spheres, d_materials, d_lights;
+	DevBuf d_tri_pos, d_tri_attr, d_tri_isect, d_tri_box, d_nodes, d_qnodes, d_spheres, d_materials, d_lights;
 	DevBuf d_morton, d_morton_tmp, d_order, d_order_tmp, d_hist, d_flags, d_parent_leaf, d_bounds, d_misc, d_ploc;
 	int num_tris = 0, num_nodes = 0, bvh_depth = 0, use_bvh = 0;
 	float bounds[6];
+	QFrame qframe;
 
 	// per-call scratch in HBM
 	DevBuf d_org, d_dir, d_hits, d_occ, d_in_a, d_in_b, d_records, d_offsets, d_keys, d_rank, d_counts;

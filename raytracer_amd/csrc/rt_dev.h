@@ -54,6 +54,23 @@ struct __attribute__((aligned(64))) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BVH node is one 64-byte line");
 
+// 32-byte traversal node: the same two child boxes on a 16-bit grid over the (padded) scene box,
+// mins rounded down and maxes up, so each quantised box contains the float box.  The traversal
+// kernels are bound by the vector-memory pipeline (TA/TD 81-87 % busy with 64-byte nodes,
+// profiles/), not by HBM or the VALU; halving the bytes per visit is what moves them.  The float
+// nodes (BvhNode) remain the build's output and what rt_hip_get_bvh returns.
+//   w0 = (l.min.x | l.min.y << 16, l.min.z | l.max.x << 16, l.max.y | l.max.z << 16, r.min.x | r.min.y << 16)
+//   w1 = (r.min.z | r.max.x << 16, r.max.y | r.max.z << 16, bits left, bits right)
+struct __attribute__((aligned(32))) QNode {
+	uint4 w0, w1;
+};
+static_assert(sizeof(QNode) == 32, "quantised node is half a BvhNode");
+
+struct QFrame {  // plane = org + q * scale, per axis
+	float org[3];
+	float scale[3];
+};
+
 // 48-byte intersection record in leaf (Morton) order: the M-T operands, nothing else.
 //   a = (v0.xyz, bits prim id), b = (e1.xyz, 0), c = (e2.xyz, 0)
 struct __attribute__((aligned(16))) TriIsect {
@@ -171,11 +188,15 @@ __device__ __forceinline__ bool mt_occlude_ref(f3 O, f3 D, f3 v0, f3 e1, f3 e2, 
 // box whose triangle the exact M-T test would accept.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Ray constants for the slab test against quantised planes: t = q * a + b with a = scale / d and
+// b = (org - o) / d, paired the way the node's 12 values pair up ((x,y) (z,x) (y,z)) so that the 12
+// multiply-adds of a node visit issue as 6 packed-FP32 FMAs.  The one rounding of the FMA against
+// terms of magnitude |org - o| / |d| displaces a plane by at most ~1e-7 of the scene extent, which
+// the 1e-5-extent padding of the boxes at build time covers (as does the outward rounding of the
+// 16-bit grid); |d| < 1e-20 is replaced by +-1e-20 before inversion (no inf, no 0 * inf NaN).
 struct RayPre {
-	// origin and reciprocal direction, pre-paired the way the node's 12 floats pair up
-	// ((x,y) (z,x) (y,z)), so that the 24 sub/mul of a node visit issue as 12 packed-FP32 ops.
-	v2f o_xy, o_zx, o_yz;
-	v2f i_xy, i_zx, i_yz;  // 1/d with |d| < 1e-20 replaced by +-1e-20 before inversion (no inf, no 0*inf NaN)
+	v2f a_xy, a_zx, a_yz;
+	v2f b_xy, b_zx, b_yz;
 };
 
 __device__ __forceinline__ float safe_rcp(float d)
@@ -186,26 +207,31 @@ __device__ __forceinline__ float safe_rcp(float d)
 
 __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 
-__device__ __forceinline__ RayPre ray_pre(f3 o, f3 d)
+__device__ __forceinline__ RayPre ray_pre(const QFrame& qf, f3 o, f3 d)
 {
 	RayPre r;
-	float ix = safe_rcp(d.x), iy = safe_rcp(d.y), iz = safe_rcp(d.z);
-	r.o_xy = mk2(o.x, o.y); r.o_zx = mk2(o.z, o.x); r.o_yz = mk2(o.y, o.z);
-	r.i_xy = mk2(ix, iy); r.i_zx = mk2(iz, ix); r.i_yz = mk2(iy, iz);
+	const float ix = safe_rcp(d.x), iy = safe_rcp(d.y), iz = safe_rcp(d.z);
+	const float ax = qf.scale[0] * ix, ay = qf.scale[1] * iy, az = qf.scale[2] * iz;
+	const float bx = (qf.org[0] - o.x) * ix, by = (qf.org[1] - o.y) * iy, bz = (qf.org[2] - o.z) * iz;
+	r.a_xy = mk2(ax, ay); r.a_zx = mk2(az, ax); r.a_yz = mk2(ay, az);
+	r.b_xy = mk2(bx, by); r.b_zx = mk2(bz, bx); r.b_yz = mk2(by, bz);
 	return r;
 }
 
+__device__ __forceinline__ v2f unpack16(uint32_t w) { return mk2((float)(w & 0xffffu), (float)(w >> 16)); }
+__device__ __forceinline__ v2f fma2(v2f q, v2f a, v2f b) { return __builtin_elementwise_fma(q, a, b); }
+
 // Both child boxes of a node against one ray.  Hit iff the widened slab interval intersects
-// [0, tlimit]; entry distances in tl / tr.  q0..q2 as laid out in BvhNode.
-__device__ __forceinline__ void slab2(const RayPre& r, float4 q0, float4 q1, float4 q2, float tlimit, bool& hl,
-                                      bool& hr, float& tl, float& tr)
+// [0, tlimit]; entry distances in tl / tr.
+__device__ __forceinline__ void slab2(const RayPre& r, uint4 w0, uint4 w1, float tlimit, bool& hl, bool& hr,
+                                      float& tl, float& tr)
 {
-	v2f a = (mk2(q0.x, q0.y) - r.o_xy) * r.i_xy;  // l: x0 y0
-	v2f b = (mk2(q0.z, q0.w) - r.o_zx) * r.i_zx;  // l: z0 x1
-	v2f c = (mk2(q1.x, q1.y) - r.o_yz) * r.i_yz;  // l: y1 z1
-	v2f d = (mk2(q1.z, q1.w) - r.o_xy) * r.i_xy;  // r: x0 y0
-	v2f e = (mk2(q2.x, q2.y) - r.o_zx) * r.i_zx;  // r: z0 x1
-	v2f f = (mk2(q2.z, q2.w) - r.o_yz) * r.i_yz;  // r: y1 z1
+	v2f a = fma2(unpack16(w0.x), r.a_xy, r.b_xy);  // l: x0 y0
+	v2f b = fma2(unpack16(w0.y), r.a_zx, r.b_zx);  // l: z0 x1
+	v2f c = fma2(unpack16(w0.z), r.a_yz, r.b_yz);  // l: y1 z1
+	v2f d = fma2(unpack16(w0.w), r.a_xy, r.b_xy);  // r: x0 y0
+	v2f e = fma2(unpack16(w1.x), r.a_zx, r.b_zx);  // r: z0 x1
+	v2f f = fma2(unpack16(w1.y), r.a_yz, r.b_yz);  // r: y1 z1
 	float tnl = fmaxf(fmaxf(fminf(a.x, b.y), fminf(a.y, c.x)), fmaxf(fminf(b.x, c.y), 0.0f));
 	float tfl = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fmaxf(b.x, c.y));
 	float tnr = fmaxf(fmaxf(fminf(d.x, e.y), fminf(d.y, f.x)), fmaxf(fminf(e.x, f.y), 0.0f));

@@ -67,7 +67,7 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 	best.v = 0.0f;
 	bool found = false;
 	if (sv.num_tris > 0) {
-		const RayPre rp = ray_pre(O, D);
+		const RayPre rp = ray_pre(sv.qframe, O, D);
 		// One loop, node or leaf per iteration ("if-if").  Measured against "while-while" (inner loop
 		// over internal nodes, leaves batched per wave) on MI355X: 0.563 ms vs 0.681 ms for the shadow
 		// rays of atrium-262k -- on 64-wide waves the lanes parked at a leaf cost more than the masked
@@ -79,13 +79,13 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 		while (cur != EXIT) {
 			bool pop;
 			if (cur >= 0) {
-				const float4* np = (const float4*)(sv.nodes + cur);
-				float4 q0 = np[0], q1 = np[1], q2 = np[2];
-				int2 ch = *((const int2*)(np + 3));
+				const uint4* np = (const uint4*)(sv.qnodes + cur);
+				const uint4 w0 = np[0], w1 = np[1];
+				const int2 ch = make_int2((int)w1.z, (int)w1.w);
 				if (CENSUS) ++cnt_nodes;
 				float tl, tr;
 				bool hl, hr;
-				slab2(rp, q0, q1, q2, ANY ? sv.tp.t_max : best.t, hl, hr, tl, tr);
+				slab2(rp, w0, w1, ANY ? sv.tp.t_max : best.t, hl, hr, tl, tr);
 				const bool right_first = hr && (!hl || tr < tl);
 				if (hl && hr) {
 					stack_push(sv, stack, stride, spill, sp, right_first ? ch.x : ch.y);
