@@ -236,11 +236,12 @@ __device__ __forceinline__ void slab2(const RayPre& r, uint4 w0, uint4 w1, float
 	float tfl = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fmaxf(b.x, c.y));
 	float tnr = fmaxf(fmaxf(fminf(d.x, e.y), fminf(d.y, f.x)), fmaxf(fminf(e.x, f.y), 0.0f));
 	float tfr = fminf(fminf(fmaxf(d.x, e.y), fmaxf(d.y, f.x)), fmaxf(e.x, f.y));
-	v2f tn = mk2(tnl, tnr) * 0.9999995f;
-	v2f tf = mk2(tfl, tfr) * 1.0000005f;
-	tl = tn.x; tr = tn.y;
-	hl = tn.x <= fminf(tf.x, tlimit);
-	hr = tn.y <= fminf(tf.y, tlimit);
+	// No multiplicative widening of [tn, tf]: every rounding in t = fma(q, a, b) displaces a plane by
+	// less than 3e-7 x (extent + |origin - scene|), and the boxes carry an absolute pad of 1e-5 x extent
+	// (plus the outward rounding of the grid), which covers it for origins within ~30 extents.
+	tl = tnl; tr = tnr;
+	hl = tnl <= fminf(tfl, tlimit);
+	hr = tnr <= fminf(tfr, tlimit);
 }
 
 // ---- wave helpers ---------------------------------------------------------------------------
