@@ -378,6 +378,68 @@ __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__
 
 // Shadow rays: one lane per (light, node); lanes of a wave share the light, so the rays of a
 // wave converge on one point.  occl[node] gets bit `light` when the ray is blocked.
+// Level 0 in one pass (sync-free driver): k_init_nodes + the gate / reflection-ray part of
+// k_light_spawn_reflect + cleared shade and shadow mask, so the G-buffer is read once and the node
+// records are written once instead of written, re-read and re-written by three launches.
+__global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, const float* __restrict__ pos_rgb,
+                                                      const float* __restrict__ nrm_rgba, int w, int h, int n0, int tile,
+                                                      int rank, int nranks, int recurse, NodeGeo* __restrict__ geo,
+                                                      NodeShade* __restrict__ shade, int* __restrict__ gate,
+                                                      unsigned int* __restrict__ occl, float* __restrict__ q_org,
+                                                      float* __restrict__ q_dir, int* __restrict__ q_parent,
+                                                      int* __restrict__ q_count, int* __restrict__ active_count)
+{
+	int j = blockIdx.x * CBLOCK + threadIdx.x;
+	bool active = false, emit = false;
+	f3 P = mk3(0, 0, 0), R = mk3(0, 0, 0);
+	if (j < n0) {
+		const int i = tile8_pixel(j, w, h);
+		int mat = -2;  // -2: padding of a partial tile, or not this rank's texel: leave the pixel alone
+		f3 N = mk3(0, 0, 0);
+		if (i >= 0) {
+			float a = nrm_rgba[4 * (size_t)i + 3];
+			mat = (a > 0.0f) ? ((int)a - 1) : -1;
+			if (mat >= sv.num_materials) mat = -1;
+			if (!tile_is_mine(i, w, tile, rank, nranks)) mat = -2;
+			P = ld3(pos_rgb + 3 * (size_t)i);
+			// decode as getRayTraceData does (c*2-1 in double, not renormalised)
+			N.x = (float)((double)nrm_rgba[4 * (size_t)i + 0] * 2.0 - 1.0);
+			N.y = (float)((double)nrm_rgba[4 * (size_t)i + 1] * 2.0 - 1.0);
+			N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
+		}
+		active = mat >= 0;
+		const f3 I = active ? normalized3(P) : mk3(0, 0, 0);
+		NodeGeo g;
+		st3(g.V, P); st3(g.N, N); st3(g.I, I);
+		g.parent = i; g.material = mat; g.branch = 0;
+		geo[j] = g;
+		NodeShade s;
+		s.pad0 = s.pad1 = s.pad2 = 0;
+		st3(s.F, mk3(0, 0, 0)); st3(s.refc, mk3(0, 0, 0)); st3(s.refrc, mk3(0, 0, 0));
+		shade[j] = s;
+		gate[j] = active ? mat : -1;
+		if (occl) occl[j] = 0u;
+		if (active && recurse && sv.materials[mat].reflectivity > 0.0f) {
+			R = I - N * (2.0f * dot3(I, N));
+			emit = true;
+		}
+	}
+	// two compactions share the workgroup's barriers: active count and reflection queue
+	__shared__ int s_cnt;
+	if (threadIdx.x == 0) s_cnt = 0;
+	__syncthreads();
+	uint64_t m = __ballot(active);
+	if (m && (threadIdx.x & 63) == 0) atomicAdd(&s_cnt, (int)__popcll(m));
+	__syncthreads();
+	if (threadIdx.x == 0 && s_cnt) atomicAdd(active_count, s_cnt);
+	int slot = block_compact_slot(emit, q_count);
+	if (emit) {
+		st3(q_org + 3 * (size_t)slot, P);
+		st3(q_dir + 3 * (size_t)slot, R);
+		q_parent[slot] = j;
+	}
+}
+
 // Optionally the launch also carries a queue of closest-hit rays (the level's reflection or
 // refraction rays): every thread first takes its share of that queue, then of the shadow rays.  On
 // its own such a queue is a short, latency-bound launch (one generation of waves, as slow as its
@@ -570,11 +632,16 @@ __global__ __launch_bounds__(BLOCK) void k_queue_sphere_hits(SceneView sv, const
 	out[i] = hi;
 }
 
-// Turn the resolved hits of a queue into child nodes of the next level.
-__global__ __launch_bounds__(CBLOCK) void k_make_children(const HitInfo* __restrict__ hi, const float* __restrict__ q_dir,
+// Turn the hits of a queue into child nodes of the next level.  `hi` holds resolved hits, or --
+// when raw_hits != nullptr -- the hits are resolved here (position, shading normal, material) and
+// `hi` is not read.  child_occl (optional): the child's shadow mask is cleared on creation.
+__global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const HitInfo* __restrict__ hi,
+                                                         const Hit* __restrict__ raw_hits,
+                                                         const float* __restrict__ q_dir,
                                                          const int* __restrict__ q_parent, int nq,
                                                          const int* __restrict__ n_ptr, int branch,
                                                          int* __restrict__ gate, NodeGeo* __restrict__ child_geo,
+                                                         unsigned int* __restrict__ child_occl,
                                                          int* __restrict__ child_count, int child_capacity,
                                                          int* __restrict__ overflow)
 {
@@ -583,7 +650,8 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(const HitInfo* __restr
 	bool hit = false;
 	HitInfo h;
 	if (i < nq) {
-		h = hi[i];
+		if (raw_hits) resolve_tri(sv, raw_hits[i], h, nullptr);
+		else h = hi[i];
 		hit = h.material >= 0;
 		if (hit && branch == 0) gate[q_parent[i]] = h.material;  // Q9: reflection hit overwrites `material`
 	}
@@ -596,6 +664,7 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(const HitInfo* __restr
 		g.material = h.material;
 		g.branch = branch;
 		child_geo[slot] = g;
+		if (child_occl) child_occl[slot] = 0u;
 	}
 }
 
@@ -960,9 +1029,6 @@ static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const flo
 	};
 	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
 	RT_HIP_CHECK(hipMemsetAsync(fc, 0, (size_t)nfc * 4, st));
-	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, n0, tile, rank,
-	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), fc + 0);
-	RT_HIP_CHECK(hipGetLastError());
 	for (int L = 0; L < bounces; ++L) {
 		const int n = (int)cap[L];
 		int* lc = fc + 8 + 8 * L;                      // this level's counters
@@ -972,10 +1038,16 @@ static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const flo
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
 		int* gate = ctx->d_gate.as<int>() + off[L];
 		unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
-		if (shadows) RT_HIP_CHECK(hipMemsetAsync(occl, 0, (size_t)n * 4, st));
-		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, n_ptr,
-		                   (const unsigned int*)nullptr, (const float*)nullptr, ctx->cfg.do_shadows, 1, recurse ? 1 : 0, gate,
-		                   q_org, q_dir, q_parent, lc + 1);
+		if (L == 0) {
+			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
+			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_pos_rgb, d_nrm_rgba, w, h, n0,
+			                   tile, rank, nranks, recurse ? 1 : 0, geo, shade, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0);
+		} else {
+			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created
+			hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, n_ptr,
+			                   (const unsigned int*)nullptr, (const float*)nullptr, ctx->cfg.do_shadows, 1, recurse ? 1 : 0, gate,
+			                   q_org, q_dir, q_parent, lc + 1);
+		}
 		RT_HIP_CHECK(hipGetLastError());
 		const int nl = sv.num_lights, nl_a = (recurse && fuse) ? nl / 2 : nl;
 		if (!recurse) {
@@ -983,29 +1055,27 @@ static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const flo
 			break;
 		}
 		NodeGeo* child_geo = ctx->d_nodes_a.as<NodeGeo>() + off[L + 1];
+		unsigned int* child_occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L + 1] : nullptr;
 		int* child_count = lc + 8;                     // = level L+1's node count
 		const int child_cap = (int)cap[L + 1];
+		const Hit* raw = nullptr;                      // fused: children are made straight from the raw hits
 		if (fuse) {
 			RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl_a, occl, lc + 1));
-			hipLaunchKernelGGL(k_resolve, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, ctx->d_hits.as<Hit>(), n, lc + 1, d_hi);
+			raw = ctx->d_hits.as<Hit>();
 		} else {
 			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr));
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 1));
 		}
-		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, n, lc + 1, 0,
-		                   gate, child_geo, child_count, child_cap, fc + 1);
+		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
+		                   lc + 1, 0, gate, child_geo, child_occl, child_count, child_cap, fc + 1);
 		// refraction, gated after the reflection hits are known (Q9)
 		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, n_ptr, gate, q_org, q_dir,
 		                   q_parent, lc + 2);
 		RT_HIP_CHECK(hipGetLastError());
-		if (fuse) {
-			RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2));
-			hipLaunchKernelGGL(k_resolve, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, ctx->d_hits.as<Hit>(), n, lc + 2, d_hi);
-		} else {
-			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
-		}
-		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, n, lc + 2, 1,
-		                   gate, child_geo, child_count, child_cap, fc + 1);
+		if (fuse) RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2));
+		else RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
+		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
+		                   lc + 2, 1, gate, child_geo, child_occl, child_count, child_cap, fc + 1);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	for (int L = bounces - 1; L >= 0; --L) {
@@ -1183,8 +1253,9 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		if (nq > 0) {
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
 			rays += nq;
-			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, nq,
-			                   (const int*)nullptr, 0, gate, child_geo, qcount + 1, 0x7fffffff, qcount + 2);
+			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
+			                   q_parent, nq, (const int*)nullptr, 0, gate, child_geo, (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
+			                   qcount + 2);
 			RT_HIP_CHECK(hipGetLastError());
 		}
 		// refraction, gated after the reflection hits are known (Q9)
@@ -1198,8 +1269,9 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		if (nq > 0) {
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
 			rays += nq;
-			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, d_hi, q_dir, q_parent, nq,
-			                   (const int*)nullptr, 1, gate, child_geo, qcount + 1, 0x7fffffff, qcount + 2);
+			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
+			                   q_parent, nq, (const int*)nullptr, 1, gate, child_geo, (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
+			                   qcount + 2);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
 			RT_HIP_CHECK(hipStreamSynchronize(st));
