@@ -39,6 +39,17 @@ for _ in range(K):
 dt = (time.perf_counter() - t0) / K
 out["process_gbuffer_host_ms"] = round(dt * 1e3, 3)
 out["process_gbuffer_host_mrays_s"] = round(pos.shape[0] / dt / 1e6, 1)
+# the C call alone (the ctypes wrapper above also copies the 125 MB of records into numpy arrays)
+import ctypes as C
+res_p, off_p, nres, nmat = C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_int(0)
+fp = C.POINTER(C.c_float)
+t0 = time.perf_counter()
+for _ in range(K):
+    g2._ck(g2.lib.rt_hip_process_gbuffer(g2.h, pos.ctypes.data_as(fp), nrm.ctypes.data_as(fp), pos.shape[0], C.byref(res_p),
+                                         C.byref(off_p), C.byref(nres), C.byref(nmat)))
+dt = (time.perf_counter() - t0) / K
+out["process_gbuffer_c_call_ms"] = round(dt * 1e3, 3)
+out["process_gbuffer_c_call_mrays_s"] = round(pos.shape[0] / dt / 1e6, 1)
 out["process_gbuffer_rays"] = int(pos.shape[0])
 out["process_gbuffer_hits"] = int(r["records"].shape[0])
 # the same call with device-resident inputs and outputs (no PCIe): processRays proper

@@ -7,7 +7,7 @@ for r in rows:
     m = re.search(r'(k_\w+(<[^>]*>)?|__amd\w+)', r['Kernel_Name'])
     seq.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), m.group(1) if m else r['Kernel_Name'][:20], r.get('Queue_Id')))
 seq.sort()
-idx = [i for i, s in enumerate(seq) if s[2] == 'k_init_nodes']
+idx = [i for i, s in enumerate(seq) if s[2] in ('k_init_spawn', 'k_init_nodes')]
 i0, i1 = idx[-3], idx[-2]
 t0 = seq[i0][0]
 prev = None
