@@ -10,9 +10,11 @@ HBM, Gen-1 shading with shadow + reflection + refraction rays, 2 bounces.
 
 A step = one frame's worth of texels per GPU.  At N GPUs the job renders N frames (N fields of
 view) per step and every frame is split over the ranks by interleaved 64x64 tiles, so each rank
-traces one frame's worth of texels (weak scaling: per-GPU work is fixed).  The scene and the LBVH
-are replicated; the only collective is the gather of the finished tiles (RCCL all_reduce of the
-disjoint RGBA8 tile images), inside the timed region.
+traces one frame's worth of texels (weak scaling: per-GPU work is fixed) -- its tiles of all N
+frames as one batch, so the launches stay frame-sized.  The scene and the LBVH
+are replicated; the only collective is the gather of the finished tiles, inside the timed region: every
+rank packs its tiles of frame f, one RCCL all-to-all sends them to rank f, which assembles frame f
+(raytracer_amd/frames.py), so only owned pixels travel.
 
 value = secondary rays issued by all ranks / wall time (barrier + synchronize on both sides, max
 over ranks).  roofline = the dominant kernel (the shadow any-hit traversal k_shadow) against HBM:
@@ -96,17 +98,25 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_DIST_BACKEND=gloo rehearses the N > 1 code path on a one-GPU box (all ranks share device 0 and the tile
+    # exchange is staged through the host); the driver's multi-GPU runs use the default, nccl = RCCL over xGMI.
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")   # where the scalar reductions live
 
     wl = WORKLOADS[args.workload]
     W, H = wl["w"], wl["h"]
     scene = scenes.cornell() if wl["tris"] == 0 else scenes.atrium(wl["tris"])
     shadow_t_max = 1.0 if args.shadow_mode == "corrected" else 0.0
-    g = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_PLOC if args.accel == "ploc" else rt.ACCEL_LBVH, device=local_rank, profile=1, bounces=2, do_shadows=1,
+    g = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_PLOC if args.accel == "ploc" else rt.ACCEL_LBVH, device=dev_index, profile=1, bounces=2, do_shadows=1,
                  shadow_t_max=shadow_t_max, use_photon_map=1 if args.photons > 0 else 0, photon_estimate=100,
                  photon_radius=1.0, seed=42)
     build_stats = g.stats()
@@ -131,17 +141,21 @@ def main():
         gb_n.append(d_n)
         gb_p.append(d_p)
     g.sync()
-    tiles = torch.zeros(nframes, npix * 4, dtype=torch.uint8, device=dev)   # this rank's tiles (others stay 0)
-    frames = torch.zeros_like(tiles)                                        # gathered frames
+    tiles = [torch.zeros(npix * 4, dtype=torch.uint8, device=dev) for _ in range(nframes)]   # this rank's tiles of each frame
+    frame = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)    # N > 1: frame `rank`, assembled from all ranks' tiles
+    xchg = None
+    if world > 1:
+        from raytracer_amd.frames import TileExchange
+        xchg = TileExchange(g, W, H, 64, rank, world, dev)
 
     def step():
-        rays = 0
-        for f in range(nframes):
-            g.render_tiles_device(gb_p[f], gb_n[f], W, H, 64, rank, world, tiles[f])
-            rays += g.last_frame_rays()
-        if world > 1:
-            frames.copy_(tiles)
-            dist.all_reduce(frames, op=dist.ReduceOp.SUM)   # tiles are disjoint: SUM assembles the frames
+        # this rank's tiles of all the step's frames in one wavefront (a batch of one at N = 1)
+        g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
+        rays = g.last_frame_rays()
+        if xchg:
+            for f in range(nframes):
+                xchg.pack(f, tiles[f])    # my tiles of frame f -> the chunk that goes to rank f
+            xchg.exchange(frame)          # one all-to-all (RCCL), then frame `rank` is complete here
         return rays
 
     def fence():
@@ -162,8 +176,8 @@ def main():
     elapsed = time.perf_counter() - t0
     st = g.stats()
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ry = torch.tensor([float(rays_rank)], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    ry = torch.tensor([float(rays_rank)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(ry, op=dist.ReduceOp.SUM)
@@ -176,8 +190,7 @@ def main():
     # census pass: same frame(s), counting node visits / triangle tests per ray (untimed)
     g.set_config(census=1, profile=0)
     g.reset_stats()
-    for f in range(nframes):
-        g.render_tiles_device(gb_p[f], gb_n[f], W, H, 64, rank, world, tiles[f])
+    g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
     cs = g.stats()
     g.set_config(census=0, profile=1)
     nodes_any = cs["census_nodes_any"] / max(cs["census_rays_any"], 1)

@@ -227,6 +227,24 @@ int rt_hip_render_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, con
  * robin) belongs to `rank` of `nranks`; other texels of d_rgba_out are left untouched. */
 int rt_hip_render_tiles_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba,
                                int width, int height, int tile, int rank, int nranks, uint8_t* d_rgba_out);
+/* The same for a batch of frames of one size (at most 16) in ONE wavefront: the three arguments are
+ * host arrays of nframes device pointers.  A rank of an N-GPU job shades its tiles of N frames per
+ * step; batching them keeps every launch frame-sized instead of 1/N-sized.  Per frame the result is
+ * what rt_hip_render_tiles_device writes, bit for bit; rt_hip_last_frame_rays() covers the batch. */
+int rt_hip_render_tiles_batch_device(rt_hip_ctx* ctx, const float* const* d_gbuf_pos_rgb,
+                                     const float* const* d_gbuf_nrm_rgba, int nframes, int width, int height,
+                                     int tile, int rank, int nranks, uint8_t* const* d_rgba_out);
+/* Tile gather without moving empty pixels (collective #2): pack the tiles listed in
+ * d_tile_list (ids ty * tiles_x + tx, ntiles of them; raytracer_amd/tiles.py: owned_tiles) from a
+ * full-size RGBA8 frame into one contiguous buffer (tile after tile, tile x tile pixels row-major,
+ * zero padding where an edge tile leaves the frame), and the inverse.  The packed buffers are what
+ * the ranks exchange (all-to-all: rank r's tiles of frame f go to rank f).  No counterpart in the
+ * reference, which has one GPU context and no tiles.  Both are enqueued on the context's stream:
+ * call rt_hip_sync() before another stream (a collective) touches the buffers. */
+int rt_hip_pack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_frame_rgba, int width, int height, int tile,
+                             const int* d_tile_list, int ntiles, uint8_t* d_packed);
+int rt_hip_unpack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_packed, int width, int height, int tile,
+                               const int* d_tile_list, int ntiles, uint8_t* d_frame_rgba);
 /* Secondary rays issued by the last frame call (shadow + reflection + refraction). */
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx);
 

@@ -62,7 +62,8 @@ ABI_SYMBOLS = [
     "rt_hip_trace_any_device", "rt_hip_gbuffer_select_device", "rt_hip_render_gbuffer_device", "rt_hip_render_frame",
     "rt_hip_render_frame_device", "rt_hip_render_tiles_device", "rt_hip_last_frame_rays", "rt_hip_photon_emit_device",
     "rt_hip_photon_set_device", "rt_hip_photon_set", "rt_hip_radiance_estimate_device", "rt_hip_radiance_estimate",
-    "rt_hip_shade_results", "rt_hip_shade_results_device",
+    "rt_hip_shade_results", "rt_hip_shade_results_device", "rt_hip_pack_tiles_device", "rt_hip_unpack_tiles_device",
+    "rt_hip_render_tiles_batch_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device",
 ]
@@ -133,6 +134,9 @@ def load_library() -> C.CDLL:
     L.rt_hip_photon_set.argtypes = [P, c_float_p, C.c_int64]
     L.rt_hip_radiance_estimate_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_float, P]
     L.rt_hip_radiance_estimate.argtypes = [P, c_float_p, c_float_p, C.c_int, C.c_int, C.c_float, c_float_p]
+    L.rt_hip_render_tiles_batch_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_pack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
+    L.rt_hip_unpack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
     L.rt_hip_shade_results.argtypes = [P, P, P, C.c_int, C.c_int, c_float_p, P]
     L.rt_hip_shade_results_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
     L.rt_hip_get_stats.argtypes = [P, C.POINTER(Stats)]
@@ -315,6 +319,19 @@ class RtHip:
     def render_tiles_device(self, d_pos_rgb, d_nrm_rgba, w, h, tile, rank, nranks, d_rgba):
         self._ck(self.lib.rt_hip_render_tiles_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, tile, rank, nranks,
                                                      _dptr(d_rgba)))
+
+    def render_tiles_batch_device(self, d_pos_list, d_nrm_list, w, h, tile, rank, nranks, d_rgba_list):
+        n = len(d_pos_list)
+        arr = C.c_void_p * n
+        self._ck(self.lib.rt_hip_render_tiles_batch_device(self.h, arr(*[_dptr(t) for t in d_pos_list]),
+                                                           arr(*[_dptr(t) for t in d_nrm_list]), n, w, h, tile, rank, nranks,
+                                                           arr(*[_dptr(t) for t in d_rgba_list])))
+
+    def pack_tiles_device(self, d_frame, w, h, tile, d_tile_list, ntiles, d_packed):
+        self._ck(self.lib.rt_hip_pack_tiles_device(self.h, _dptr(d_frame), w, h, tile, _dptr(d_tile_list), ntiles, _dptr(d_packed)))
+
+    def unpack_tiles_device(self, d_packed, w, h, tile, d_tile_list, ntiles, d_frame):
+        self._ck(self.lib.rt_hip_unpack_tiles_device(self.h, _dptr(d_packed), w, h, tile, _dptr(d_tile_list), ntiles, _dptr(d_frame)))
 
     def render_frame(self, pos_rgb, nrm_rgba, w, h):
         pos_rgb, nrm_rgba = _f(pos_rgb), _f(nrm_rgba)

@@ -381,8 +381,20 @@ __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__
 // Level 0 in one pass (sync-free driver): k_init_nodes + the gate / reflection-ray part of
 // k_light_spawn_reflect + cleared shade and shadow mask, so the G-buffer is read once and the node
 // records are written once instead of written, re-read and re-written by three launches.
-__global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, const float* __restrict__ pos_rgb,
-                                                      const float* __restrict__ nrm_rgba, int w, int h, int n0, int tile,
+// Level-0 node j of a frame -> pixel.  Without a tile list: 8x8 blocks of the whole frame.  With
+// one: the rank's own tiles one after the other, 8x8 blocks inside each tile (tile % 8 == 0).
+__device__ __forceinline__ int level0_pixel(const FrameSet& fs, int jj, int w, int h, int tile)
+{
+	if (!fs.tile_list) return tile8_pixel(jj, w, h);
+	const int t2 = tile * tile, tiles_x = (w + tile - 1) / tile, sub_x = tile >> 3;
+	const int id = fs.tile_list[jj / t2], r = jj % t2;
+	const int sub = r >> 6, k = r & 63;
+	const int x = (id % tiles_x) * tile + ((sub % sub_x) << 3) + (k & 7);
+	const int y = (id / tiles_x) * tile + ((sub / sub_x) << 3) + (k >> 3);
+	return (x < w && y < h) ? y * w + x : -1;
+}
+
+__global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs, int w, int h, int n0, int tile,
                                                       int rank, int nranks, int recurse, NodeGeo* __restrict__ geo,
                                                       NodeShade* __restrict__ shade, int* __restrict__ gate,
                                                       unsigned int* __restrict__ occl, float* __restrict__ q_org,
@@ -393,7 +405,10 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, const float
 	bool active = false, emit = false;
 	f3 P = mk3(0, 0, 0), R = mk3(0, 0, 0);
 	if (j < n0) {
-		const int i = tile8_pixel(j, w, h);
+		const int f = j / fs.per_frame;
+		const int i = level0_pixel(fs, j - f * fs.per_frame, w, h, tile);
+		const float* __restrict__ pos_rgb = fs.pos[f];
+		const float* __restrict__ nrm_rgba = fs.nrm[f];
 		int mat = -2;  // -2: padding of a partial tile, or not this rank's texel: leave the pixel alone
 		f3 N = mk3(0, 0, 0);
 		if (i >= 0) {
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, const float
 		const f3 I = active ? normalized3(P) : mk3(0, 0, 0);
 		NodeGeo g;
 		st3(g.V, P); st3(g.N, N); st3(g.I, I);
-		g.parent = i; g.material = mat; g.branch = 0;
+		g.parent = i < 0 ? -1 : f * (w * h) + i; g.material = mat; g.branch = 0;
 		geo[j] = g;
 		NodeShade s;
 		s.pad0 = s.pad1 = s.pad2 = 0;
@@ -673,7 +688,7 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
 __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* __restrict__ geo,
                                                    const NodeShade* __restrict__ shade, int n,
                                                    const int* __restrict__ n_ptr, int level,
-                                                   NodeShade* __restrict__ parent_shade, uint8_t* __restrict__ rgba,
+                                                   NodeShade* __restrict__ parent_shade, FrameSet fs, int frame_pixels,
                                                    float* __restrict__ rgb_float, int lit,
                                                    const unsigned int* __restrict__ occl)
 {
@@ -700,7 +715,8 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 		float* dst = g.branch == 0 ? parent_shade[g.parent].refc : parent_shade[g.parent].refrc;
 		st3(dst, col);
 	} else {
-		uint8_t* px = rgba + 4 * (size_t)g.parent;
+		const int f = g.parent / frame_pixels, pixel = g.parent - f * frame_pixels;  // level 0: parent = frame * pixels + pixel
+		uint8_t* px = fs.rgba[f] + 4 * (size_t)pixel;
 		if (g.material >= 0) {
 			px[0] = (uint8_t)min((int)col.x, 255);
 			px[1] = (uint8_t)min((int)col.y, 255);
@@ -709,7 +725,7 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 		} else {
 			px[0] = px[1] = px[2] = px[3] = 0;
 		}
-		if (rgb_float) st3(rgb_float + 3 * (size_t)g.parent, col);
+		if (rgb_float) st3(rgb_float + 3 * (size_t)pixel, col);
 	}
 }
 
@@ -767,9 +783,43 @@ __global__ __launch_bounds__(BLOCK) void k_shade_results(SceneView sv, const rt_
 	}
 }
 
+// ---- packed tile exchange (multi-GPU tile gather) ------------------------------------------------
+// One lane per packed pixel: slot p belongs to tile tile_list[p / tile^2]; pixels of an edge tile
+// outside the frame are padding (zero when packing, skipped when unpacking).
+template <bool PACK>
+__global__ __launch_bounds__(BLOCK) void k_tiles_pack(uint32_t* __restrict__ frame, int w, int h, int tile,
+                                                      const int* __restrict__ tile_list, int ntiles,
+                                                      uint32_t* __restrict__ packed)
+{
+	const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	const int t2 = tile * tile;
+	if (p >= (int64_t)ntiles * t2) return;
+	const int tiles_x = (w + tile - 1) / tile;
+	const int id = tile_list[p / t2], k = (int)(p % t2);
+	const int x = (id % tiles_x) * tile + k % tile, y = (id / tiles_x) * tile + k / tile;
+	const bool inside = x < w && y < h;
+	if (PACK) packed[p] = inside ? frame[(size_t)y * w + x] : 0u;
+	else if (inside) frame[(size_t)y * w + x] = packed[p];
+}
+
 }  // namespace
 
 // ================================================================================================
+int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, int h, int tile, const int* d_tile_list,
+                         int ntiles, uint8_t* d_packed)
+{
+	const int64_t n = (int64_t)ntiles * tile * tile;
+	if (n <= 0) return RT_HIP_OK;
+	if (pack)
+		hipLaunchKernelGGL(k_tiles_pack<true>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream,
+		                   (uint32_t*)d_frame, w, h, tile, d_tile_list, ntiles, (uint32_t*)d_packed);
+	else
+		hipLaunchKernelGGL(k_tiles_pack<false>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream,
+		                   (uint32_t*)d_frame, w, h, tile, d_tile_list, ntiles, (uint32_t*)d_packed);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
 int rt_launch_shade_results(rt_hip_ctx* ctx, const rt_ray* d_rec, int n, const rt_result_offset* d_groups, int ngroups,
                             float* d_rgb, uint8_t* d_rgb8)
 {
@@ -964,15 +1014,44 @@ static int trace_queue(rt_hip_ctx* ctx, const SceneView& sv, const float* q_org,
 constexpr int64_t FRAME_LEVEL_CAP = (int64_t)1 << 23;      // nodes per level
 constexpr int64_t FRAME_TOTAL_CAP = (int64_t)3 << 23;      // nodes per frame (about 2.5 GB of level arrays)
 
-static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
-                              int rank, int nranks, uint8_t* d_rgba, bool* overflowed, bool* declined)
+// The rank's own tiles as a device list (cached per frame geometry); used when the tile size lets a
+// tile be cut into 8x8 blocks.
+static int owned_tile_list(rt_hip_ctx* ctx, int w, int h, int tile, int rank, int nranks, const int** d_list, int* count)
+{
+	const int key[5] = {w, h, tile, rank, nranks};
+	if (memcmp(key, ctx->tile_key, sizeof(key)) != 0 || !ctx->d_tile_list.p) {
+		const int tiles_x = (w + tile - 1) / tile, tiles_y = (h + tile - 1) / tile;
+		std::vector<int> ids;
+		for (int ty = 0; ty < tiles_y; ++ty)
+			for (int tx = 0; tx < tiles_x; ++tx)
+				if ((tx + ty) % nranks == rank) ids.push_back(ty * tiles_x + tx);
+		RT_CHECK(ctx->d_tile_list.reserve(std::max<size_t>(ids.size(), 1) * sizeof(int)));
+		if (!ids.empty()) RT_HIP_CHECK(hipMemcpy(ctx->d_tile_list.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+		memcpy(ctx->tile_key, key, sizeof(key));
+		ctx->tile_count = (int)ids.size();
+	}
+	*d_list = ctx->d_tile_list.as<int>();
+	*count = ctx->tile_count;
+	return RT_HIP_OK;
+}
+
+static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int tile, int rank, int nranks,
+                              bool* overflowed, bool* declined)
 {
 	*overflowed = false;
 	*declined = true;
 	hipStream_t st = ctx->stream;
 	SceneView sv = rt_scene_view(ctx);
 	const int bounces = ctx->cfg.bounces;
-	const int n0 = tile8_count(w, h);
+	fs.tile_list = nullptr; fs.ntiles = 0;
+	fs.per_frame = tile8_count(w, h);
+	if (nranks > 1 && tile % 8 == 0) {
+		RT_CHECK(owned_tile_list(ctx, w, h, tile, rank, nranks, &fs.tile_list, &fs.ntiles));
+		fs.per_frame = fs.ntiles * tile * tile;
+	}
+	if ((int64_t)fs.per_frame * fs.nframes > FRAME_LEVEL_CAP) return RT_HIP_OK;
+	const int n0 = fs.per_frame * fs.nframes;
+	if (n0 == 0) { *declined = false; return RT_HIP_OK; }  // this rank owns no tile
 	std::vector<int64_t> cap(bounces), off(bounces + 1, 0);
 	for (int L = 0; L < bounces; ++L) {
 		cap[L] = L == 0 ? n0 : std::min<int64_t>(2 * cap[L - 1], FRAME_LEVEL_CAP);
@@ -1040,7 +1119,7 @@ static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const flo
 		unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
 		if (L == 0) {
 			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
-			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_pos_rgb, d_nrm_rgba, w, h, n0,
+			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, fs, w, h, n0,
 			                   tile, rank, nranks, recurse ? 1 : 0, geo, shade, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0);
 		} else {
 			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created
@@ -1085,7 +1164,7 @@ static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const flo
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + off[L - 1] : nullptr;
 		const unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
 		hipLaunchKernelGGL(k_combine, dim3(nblocks((int)cap[L], BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, (int)cap[L], n_ptr, L,
-		                   pshade, d_rgba, (float*)nullptr, 1, occl);
+		                   pshade, fs, w * h, (float*)nullptr, 1, occl);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	int* h_fc = (int*)ctx->h_small;  // 4 KiB pinned; nfc <= 80 ints
@@ -1111,7 +1190,7 @@ static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const flo
 	float ms = 0;
 	RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
 	ctx->stats.frame_ms += ms;
-	ctx->stats.frames += 1;
+	ctx->stats.frames += fs.nframes;
 	ctx->last_frame_rays = rays_any + rays_closest;
 	ctx->last_count = levels;
 	RT_CHECK(rt_collect_timing(ctx));
@@ -1121,12 +1200,13 @@ static int render_frame_async(rt_hip_ctx* ctx, const float* d_pos_rgb, const flo
 static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
                              int rank, int nranks, uint8_t* d_rgba);
 
-int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
-                    int rank, int nranks, uint8_t* d_rgba)
+int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
+                     int h, int tile, int rank, int nranks, uint8_t* const* d_rgba)
 {
 	ctx->last_frame_rays = 0;
-	if (w <= 0 || h <= 0 || ctx->cfg.bounces <= 0) return RT_HIP_OK;
-	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 28) { rt_set_error("frame larger than 2^28 texels"); return RT_HIP_ERR_LIMIT; }
+	if (w <= 0 || h <= 0 || nframes <= 0 || ctx->cfg.bounces <= 0) return RT_HIP_OK;
+	if (nframes > RT_MAX_BATCH) { rt_set_error("more than %d frames in a batch", RT_MAX_BATCH); return RT_HIP_ERR_LIMIT; }
+	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 26) { rt_set_error("frame larger than 2^26 texels"); return RT_HIP_ERR_LIMIT; }
 	if (ctx->cfg.bounces > 8) { rt_set_error("bounces > 8 not supported"); return RT_HIP_ERR_LIMIT; }
 	if ((int)ctx->lights.size() > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
 	// The photon gather takes its point count on the host, so photon-mapped frames stay on the
@@ -1134,11 +1214,28 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 	const char* e = getenv("RT_HIP_FRAME_SYNC");
 	const int force_sync = e ? atoi(e) : 0;
 	if (!ctx->cfg.use_photon_map && !force_sync) {
+		FrameSet fs;
+		memset(&fs, 0, sizeof(fs));
+		fs.nframes = nframes;
+		for (int f = 0; f < nframes; ++f) { fs.pos[f] = d_pos_rgb[f]; fs.nrm[f] = d_nrm_rgba[f]; fs.rgba[f] = d_rgba[f]; }
 		bool overflowed = false, declined = false;
-		RT_CHECK(render_frame_async(ctx, d_pos_rgb, d_nrm_rgba, w, h, tile, rank, nranks, d_rgba, &overflowed, &declined));
+		RT_CHECK(render_frame_async(ctx, fs, w, h, tile, rank, nranks, &overflowed, &declined));
 		if (!overflowed && !declined) return RT_HIP_OK;
 	}
-	return render_frame_sync(ctx, d_pos_rgb, d_nrm_rgba, w, h, tile, rank, nranks, d_rgba);
+	// frame by frame, every level sized on the host
+	int64_t rays = 0;
+	for (int f = 0; f < nframes; ++f) {
+		RT_CHECK(render_frame_sync(ctx, d_pos_rgb[f], d_nrm_rgba[f], w, h, tile, rank, nranks, d_rgba[f]));
+		rays += ctx->last_frame_rays;
+	}
+	ctx->last_frame_rays = rays;
+	return RT_HIP_OK;
+}
+
+int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
+                    int rank, int nranks, uint8_t* d_rgba)
+{
+	return rt_render_frames(ctx, &d_pos_rgb, &d_nrm_rgba, 1, w, h, tile, rank, nranks, &d_rgba);
 }
 
 static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
@@ -1148,6 +1245,9 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 	SceneView sv = rt_scene_view(ctx);
 	const int bounces = ctx->cfg.bounces;
 	const int npix = tile8_count(w, h);  // level-0 nodes: the frame padded to whole 8x8 tiles
+	FrameSet fs1;                        // k_combine's output description: this one frame
+	memset(&fs1, 0, sizeof(fs1));
+	fs1.nframes = 1; fs1.per_frame = npix; fs1.rgba[0] = d_rgba;
 	const bool spheres = sv.num_spheres > 0 && sv.num_tris == 0;
 
 	// level arrays: level L can hold at most 2^L * npix nodes, but only what was spawned is used;
@@ -1289,7 +1389,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + geo_off[L];
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + geo_off[L - 1] : nullptr;
 		hipLaunchKernelGGL(k_combine, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, (const int*)nullptr, L,
-		                   pshade, d_rgba, (float*)nullptr, 0, (const unsigned int*)nullptr);
+		                   pshade, fs1, w * h, (float*)nullptr, 0, (const unsigned int*)nullptr);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));

@@ -301,7 +301,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_hits, &ctx->d_occ, &ctx->d_in_a, &ctx->d_in_b, &ctx->d_records, &ctx->d_offsets, &ctx->d_keys,
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
-	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc};
+	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);
@@ -645,6 +645,21 @@ int rt_hip_render_tiles_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, con
 	return rt_render_frame(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, tile, rank, nranks, d_rgba_out);
 }
 
+int rt_hip_render_tiles_batch_device(rt_hip_ctx* ctx, const float* const* d_gbuf_pos_rgb, const float* const* d_gbuf_nrm_rgba,
+                                     int nframes, int width, int height, int tile, int rank, int nranks,
+                                     uint8_t* const* d_rgba_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || nframes <= 0 || !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_rgba_out || tile <= 0 ||
+	    nranks <= 0 || rank < 0 || rank >= nranks) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	for (int f = 0; f < nframes; ++f)
+		if (!d_gbuf_pos_rgb[f] || !d_gbuf_nrm_rgba[f] || !d_rgba_out[f]) { rt_set_error("frame %d: null buffer", f); return RT_HIP_ERR_ARG; }
+	return rt_render_frames(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, nframes, width, height, tile, rank, nranks, d_rgba_out);
+}
+
 int rt_hip_render_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
                                int height, uint8_t* d_rgba_out)
 {
@@ -727,6 +742,36 @@ int rt_hip_radiance_estimate(rt_hip_ctx* ctx, const float* pos, const float* nrm
 	RT_HIP_CHECK(hipMemcpyAsync(rgb_out, ctx->d_accum.p, (size_t)npts * 12, hipMemcpyDeviceToHost, st));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	return RT_HIP_OK;
+}
+
+// ---- packed tile exchange --------------------------------------------------------------------------
+static int check_tiles_args(const void* frame, int w, int h, int tile, const int* d_tile_list, int ntiles, const void* packed)
+{
+	if (w <= 0 || h <= 0 || tile <= 0 || tile > 1024 || ntiles < 0 || (ntiles > 0 && (!frame || !d_tile_list || !packed))) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	if ((int64_t)ntiles > (int64_t)((w + tile - 1) / tile) * ((h + tile - 1) / tile)) {
+		rt_set_error("%d tiles listed, the frame has %d", ntiles, ((w + tile - 1) / tile) * ((h + tile - 1) / tile));
+		return RT_HIP_ERR_ARG;
+	}
+	return RT_HIP_OK;
+}
+
+int rt_hip_pack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_frame_rgba, int width, int height, int tile,
+                             const int* d_tile_list, int ntiles, uint8_t* d_packed)
+{
+	RT_CHECK(check_ctx(ctx));
+	RT_CHECK(check_tiles_args(d_frame_rgba, width, height, tile, d_tile_list, ntiles, d_packed));
+	return rt_launch_tiles_pack(ctx, true, (uint8_t*)d_frame_rgba, width, height, tile, d_tile_list, ntiles, d_packed);
+}
+
+int rt_hip_unpack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_packed, int width, int height, int tile,
+                               const int* d_tile_list, int ntiles, uint8_t* d_frame_rgba)
+{
+	RT_CHECK(check_ctx(ctx));
+	RT_CHECK(check_tiles_args(d_frame_rgba, width, height, tile, d_tile_list, ntiles, d_packed));
+	return rt_launch_tiles_pack(ctx, false, d_frame_rgba, width, height, tile, d_tile_list, ntiles, (uint8_t*)d_packed);
 }
 
 // ---- live shading of hit records -----------------------------------------------------------------

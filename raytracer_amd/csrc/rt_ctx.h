@@ -77,6 +77,21 @@ struct SceneView {
 	TraceParams tp;
 };
 
+// A batch of frames shaded in one wavefront (same size, same scene): the G-buffers in, the RGBA8
+// images out.  Level-0 node j belongs to frame j / per_frame; a level-0 node's `parent` is
+// frame * (w * h) + pixel.  With a tile list (multi-GPU split, tile % 8 == 0) only the rank's own
+// tiles become nodes, so every kernel of the frame shrinks with 1 / nranks.
+constexpr int RT_MAX_BATCH = 16;
+struct FrameSet {
+	const float* pos[RT_MAX_BATCH];
+	const float* nrm[RT_MAX_BATCH];
+	uint8_t* rgba[RT_MAX_BATCH];
+	int nframes;
+	int per_frame;         // level-0 nodes per frame
+	const int* tile_list;  // owned tile ids (ty * tiles_x + tx), or nullptr: every 8x8 block of the frame
+	int ntiles;
+};
+
 struct rt_hip_ctx {
 	rt_hip_config cfg;
 	hipStream_t stream = nullptr;
@@ -84,7 +99,9 @@ struct rt_hip_ctx {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;  // pending (profile mode)
 	std::vector<int> trace_event_class;                           // 0 closest, 1 any
 	size_t trace_events_used = 0;
-	DevBuf d_census, d_spill;
+	DevBuf d_census, d_spill, d_tile_list;
+	int tile_key[5] = {0, 0, 0, 0, 0};                            // (w, h, tile, rank, nranks) of d_tile_list
+	int tile_count = 0;
 	int max_trace_threads = 0;  // grid cap of the trace kernels = RT_TRACE_OVERSUB x resident-thread capacity
 
 	std::vector<HostMesh> meshes;
@@ -168,9 +185,13 @@ int rt_gbuffer_select(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_p
                       int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* out_count);
 int rt_launch_shade_results(rt_hip_ctx* ctx, const rt_ray* d_rec, int n, const rt_result_offset* d_groups, int ngroups,
                             float* d_rgb, uint8_t* d_rgb8);
+int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, int h, int tile, const int* d_tile_list,
+                         int ntiles, uint8_t* d_packed);
 int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb);
 int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
                     int rank, int nranks, uint8_t* d_rgba);
+int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
+                     int h, int tile, int rank, int nranks, uint8_t* const* d_rgba);
 
 // ---- k_photon.hip --------------------------------------------------------------------------------
 int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count, float* d_out, int64_t capacity,

@@ -1,0 +1,48 @@
+"""Host side of the tile gather (collective #2).
+
+With N GPUs a step renders N frames; every frame is split over the ranks by interleaved tiles
+(`tiles.tile_owner`), and frame f is assembled on rank f.  Each rank packs its tiles of frame f into
+one contiguous chunk (`rt_hip_pack_tiles_device`), one all-to-all moves chunk f to rank f, and the
+receiver scatters the N chunks into its frame (`rt_hip_unpack_tiles_device`).  Only owned pixels
+travel: (N-1)/N of one frame per rank and step (7.3 MB at 1080p, N = 8), not N full frames as an
+all-reduce of sparse images would move.  RCCL over xGMI on the GPU box, gloo in the CPU tests (where
+`tiles.pack_tiles` / `unpack_tiles` stand in for the kernels).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .tiles import max_owned_tiles, owned_tiles
+
+
+class TileExchange:
+    def __init__(self, ctx, width, height, tile, rank, world, device, group=None):
+        self.ctx, self.w, self.h, self.tile, self.rank, self.world, self.group = ctx, width, height, tile, rank, world, group
+        lists = [owned_tiles(width, height, tile, r, world) for r in range(world)]
+        self.ntiles = [int(len(l)) for l in lists]
+        self.chunk = max_owned_tiles(width, height, tile, world) * tile * tile * 4   # bytes, equal splits
+        self.d_lists = [torch.from_numpy(np.ascontiguousarray(l)).to(device) for l in lists]
+        self.send = torch.zeros(world * self.chunk, dtype=torch.uint8, device=device)
+        self.recv = torch.zeros(world * self.chunk, dtype=torch.uint8, device=device)
+
+    def pack(self, frame_index, d_tiles_rgba):
+        """Queue this rank's tiles of frame `frame_index` (full-size image, own tiles filled in)."""
+        c = self.chunk
+        self.ctx.pack_tiles_device(d_tiles_rgba, self.w, self.h, self.tile, self.d_lists[self.rank], self.ntiles[self.rank],
+                                   self.send[frame_index * c:(frame_index + 1) * c])
+
+    def exchange(self, d_frame_rgba):
+        """All-to-all of the packed chunks, then assemble frame `rank` in d_frame_rgba."""
+        self.ctx.sync()                                           # packs done before the collective reads them
+        if dist.get_backend(self.group) == "gloo":                # rehearsal on a box without RCCL peers: stage through the host
+            recv = torch.zeros(self.recv.shape, dtype=torch.uint8)
+            dist.all_to_all_single(recv, self.send.cpu(), group=self.group)
+            self.recv.copy_(recv)
+        else:
+            dist.all_to_all_single(self.recv, self.send, group=self.group)
+        torch.cuda.current_stream().synchronize()                 # chunks landed before the context's stream reads them
+        c = self.chunk
+        for r in range(self.world):
+            self.ctx.unpack_tiles_device(self.recv[r * c:(r + 1) * c], self.w, self.h, self.tile, self.d_lists[r], self.ntiles[r],
+                                         d_frame_rgba)
+        self.ctx.sync()

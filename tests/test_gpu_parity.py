@@ -440,3 +440,72 @@ def test_incoherent_rays_bvh_equals_exhaustive(rt, accel, spread):
     assert_bits_equal(a["hits"]["t"][hit], b["hits"]["t"][hit], "t")
     assert_bits_equal(a["hits"]["u"][hit], b["hits"]["u"][hit], "u")
     assert occ_b.shape[0] == 4096
+
+
+def test_pack_unpack_tiles_kernels(rt):
+    """rt_hip_pack_tiles_device / rt_hip_unpack_tiles_device against their numpy mirror (tiles.py)."""
+    torch = _torch()
+    from raytracer_amd.tiles import owned_tiles, pack_tiles, unpack_tiles
+    w, h, tile, n = 100, 75, 16, 3
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, (w * h, 4)).astype(np.uint8)
+    g = rt.RtHip(scenes.cornell())
+    d_img = torch.from_numpy(img.copy()).cuda()
+    d_out = torch.full((w * h, 4), 9, dtype=torch.uint8, device="cuda")
+    for r in range(n):
+        ids = owned_tiles(w, h, tile, r, n)
+        d_ids = torch.from_numpy(ids).cuda()
+        d_packed = torch.full((len(ids) * tile * tile, 4), 5, dtype=torch.uint8, device="cuda")
+        g.pack_tiles_device(d_img, w, h, tile, d_ids, len(ids), d_packed)
+        g.sync()
+        np.testing.assert_array_equal(d_packed.cpu().numpy(), pack_tiles(img, w, h, tile, ids))
+        g.unpack_tiles_device(d_packed, w, h, tile, d_ids, len(ids), d_out)
+        g.sync()
+    np.testing.assert_array_equal(d_out.cpu().numpy(), img)
+    with pytest.raises(rt.RtHipError):
+        g.pack_tiles_device(d_img, w, h, tile, d_ids, 10_000, d_packed)   # more tiles than the frame has
+    g.close()
+
+
+@pytest.mark.parametrize("nranks,tile", [(3, 16), (2, 24), (4, 20)], ids=["3x16", "2x24", "4x20-not-8-divisible"])
+def test_render_tiles_batch_equals_single_frames(rt, oracle_cls, nranks, tile):
+    """A batch of frames in one wavefront (what a rank of an N-GPU job runs per step) writes, per frame,
+    exactly what one rt_hip_render_tiles_device call per frame writes -- also with the level-0 nodes
+    compacted to the rank's own tiles (tile % 8 == 0) -- and the ranks together give the whole frames."""
+    torch = _torch()
+    sc = scenes.cornell()
+    orc = oracle_cls(sc)
+    w, h = 100, 75
+    g = rt.RtHip(sc, semantics="array", do_shadows=1, shadow_t_max=1.0)
+    gb = []
+    for f in range(3):
+        nr, po = orc.software_gbuffer(w, h, fov=sc.fov - 0.04 * f)
+        gb.append((torch.from_numpy(po).cuda(), torch.from_numpy(nr).cuda()))
+    full = []
+    for d_p, d_n in gb:
+        img = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+        g.render_frame_device(d_p, d_n, w, h, img)
+        full.append(img.cpu().numpy())
+    union = [np.full(w * h * 4, 7, np.uint8) for _ in gb]
+    total_rays = 0
+    for r in range(nranks):
+        single, rays_single = [], 0
+        for d_p, d_n in gb:
+            img = torch.full((w * h * 4,), 7, dtype=torch.uint8, device="cuda")
+            g.render_tiles_device(d_p, d_n, w, h, tile, r, nranks, img)
+            rays_single += g.last_frame_rays()
+            single.append(img.cpu().numpy())
+        outs = [torch.full((w * h * 4,), 7, dtype=torch.uint8, device="cuda") for _ in gb]
+        g.render_tiles_batch_device([p for p, _ in gb], [n for _, n in gb], w, h, tile, r, nranks, outs)
+        assert g.last_frame_rays() == rays_single
+        total_rays += rays_single
+        for f in range(3):
+            got = outs[f].cpu().numpy()
+            np.testing.assert_array_equal(got, single[f])
+            mine = got != 7
+            union[f][mine] = got[mine]
+    from raytracer_amd.tiles import tile_owner
+    for f in range(3):
+        # every pixel was written by exactly the rank that owns it (7 never survives: alpha is 0 or 255)
+        np.testing.assert_array_equal(union[f], full[f])
+    g.close()

@@ -1,6 +1,7 @@
 """The N>1 path on CPU: two gloo ranks shade their interleaved tiles (with the oracle standing in
-for the GPU) and assemble the frame exactly as bench.py does (all_reduce SUM of disjoint RGBA8 tile
-images); the result must equal the single-rank frame bit for bit.  Also the photon index shards."""
+for the GPU) and assemble the frames exactly as bench.py does (packed tiles, one all-to-all, frame f
+assembled on rank f); the result must equal the single-rank frames bit for bit.  Also the older
+all_reduce form, the photon index shards and the photon all-gather."""
 import os
 import socket
 
@@ -10,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from raytracer_amd import scenes
-from raytracer_amd.tiles import photon_shard, tile_owner
+from raytracer_amd.tiles import max_owned_tiles, owned_tiles, pack_tiles, photon_shard, tile_owner, unpack_tiles
 
 W, H, TILE = 96, 64, 16
 
@@ -123,3 +124,76 @@ def test_two_rank_photon_gather_equals_single_rank(tmp_path):
         got = np.load(os.path.join(str(tmp_path), "photons_%d.npy" % r))
         assert got.tobytes() == whole.tobytes()          # every rank holds the single-rank array, bit for bit
         assert np.load(os.path.join(str(tmp_path), "empty_%d.npy" % r)).shape == (0, 9)
+
+
+# ---- collective #2 as bench.py runs it: packed tiles, all-to-all, frame f assembled on rank f --------
+W2, H2, TILE2 = 100, 75, 16          # not multiples of the tile: edge tiles carry padding
+
+
+def _frame_inputs_fov(fov_delta):
+    from oracle.pyoracle import Oracle
+    sc = scenes.cornell()
+    orc = Oracle(sc)
+    nr, po = orc.software_gbuffer(W2, H2, fov=sc.fov + fov_delta)
+    mid = nr[:, 3].astype(np.int32) - 1
+    nrm = (nr[:, :3].astype(np.float64) * 2.0 - 1.0).astype(np.float32)
+    return orc, po, nrm, mid
+
+
+def _a2a_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owner = tile_owner(W2, H2, TILE2, world)
+    mine = owner == rank
+    lists = [owned_tiles(W2, H2, TILE2, r, world) for r in range(world)]
+    chunk = max_owned_tiles(W2, H2, TILE2, world) * TILE2 * TILE2 * 4
+    send = torch.zeros(world * chunk, dtype=torch.uint8)
+    for f in range(world):                                         # a step = `world` frames
+        orc, po, nrm, mid = _frame_inputs_fov(-0.03 * f)
+        rgba, _, _ = orc.render_texels(po, nrm, np.where(mine, mid, -1), bounces=2, do_shadows=1, shadow_t_max=1.0)
+        tiles = np.where(mine[:, None], rgba, 7).astype(np.uint8)  # 7 = "untouched" pixels of other ranks: must not travel
+        packed = pack_tiles(tiles, W2, H2, TILE2, lists[rank]).reshape(-1)
+        send[f * chunk: f * chunk + packed.shape[0]] = torch.from_numpy(packed)
+    recv = torch.zeros_like(send)
+    dist.all_to_all_single(recv, send)
+    frame = np.full((W2 * H2, 4), 9, np.uint8)
+    for r in range(world):
+        unpack_tiles(recv[r * chunk:(r + 1) * chunk].numpy(), W2, H2, TILE2, lists[r], frame)
+    dist.barrier()
+    np.save(os.path.join(out_dir, "frame_%d.npy" % rank), frame)
+    dist.destroy_process_group()
+
+
+def test_owned_tiles_match_tile_owner():
+    for n in (1, 2, 3, 8):
+        owner = tile_owner(W2, H2, TILE2, n).reshape(H2, W2)
+        tiles_x = -(-W2 // TILE2)
+        seen = []
+        for r in range(n):
+            ids = owned_tiles(W2, H2, TILE2, r, n)
+            assert list(ids) == sorted(ids)
+            for t in ids:
+                ty, tx = divmod(int(t), tiles_x)
+                assert owner[ty * TILE2, tx * TILE2] == r
+            seen += list(ids)
+        assert sorted(seen) == list(range(tiles_x * -(-H2 // TILE2)))
+
+
+def test_pack_unpack_roundtrip():
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (W2 * H2, 4)).astype(np.uint8)
+    out = np.zeros_like(img)
+    for r in range(3):
+        ids = owned_tiles(W2, H2, TILE2, r, 3)
+        unpack_tiles(pack_tiles(img, W2, H2, TILE2, ids), W2, H2, TILE2, ids, out)
+    np.testing.assert_array_equal(out, img)
+
+
+def test_two_rank_packed_exchange_assembles_frame_f_on_rank_f(tmp_path):
+    mp.spawn(_a2a_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for f in range(2):
+        orc, po, nrm, mid = _frame_inputs_fov(-0.03 * f)
+        full, _, _ = orc.render_texels(po, nrm, mid, bounces=2, do_shadows=1, shadow_t_max=1.0)
+        got = np.load(os.path.join(str(tmp_path), "frame_%d.npy" % f))
+        np.testing.assert_array_equal(got, full)
