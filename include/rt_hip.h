@@ -248,6 +248,26 @@ int rt_hip_unpack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_packed, int wid
 /* Secondary rays issued by the last frame call (shadow + reflection + refraction). */
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx);
 
+/* ---- the live (Gen-2) frame: SURVEY.md 8f row 2 ---------------------------------------------- */
+/* Scene::draw (data/scene.cpp:40-56) from the G-buffer on, entirely on the device:
+ *   getRayTraceData's selection (texel i with alpha > 0 and, for interlace > 1, i % interlace == phase;
+ *     ras_rasterizer.cpp:509-536),
+ *   processRays' ray generation and closest hit (rt_raytracer.cpp:444-455, 507),
+ *   drawRayData (ras_rasterizer.cpp:619-669): each hit shaded by mesh_fs at the hit point with the
+ *     hit's material and written as RGB8 into the raypass image at the texel its ray came from;
+ *     misses write nothing; the image persists across calls so the phases accumulate, and the
+ *     caller fills it with 255 once (the reference clears it to white on the first pass only, :632-634),
+ *   drawMeshes (:237-281, mesh_fs.cpp:46-47): colour = refl * raypass + (1 - refl) * direct at every
+ *     covered texel with the visible surface's material (alpha - 1), background = clear colour 0.3.
+ * Deliberate differences from the GL path: prepass scale 1 (raypass and frame have one size); the
+ * point lands on the texel it came from (no FP16 reprojection jitter); the forward pass shades the
+ * G-buffer's position/normal rather than re-rasterised vertex attributes; each group is drawn with
+ * its own count (the reference passes the cumulative offset as the count, :660); untextured.
+ * d_raypass_rgb8: width * height * 3 bytes; d_rgba_out: width * height * 4; *out_rays = rays traced. */
+int rt_hip_live_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba,
+                             int width, int height, int interlace, int phase, uint8_t* d_raypass_rgb8,
+                             uint8_t* d_rgba_out, int* out_rays);
+
 /* ---- live shading of the hit records (the raypass) ------------------------------------------ */
 /* rasterizer/shaders/mesh_fs.cpp:26-49 evaluated at each hit record the way Rasterizer::drawRayData
  * (ras_rasterizer.cpp:619-669) draws it: one point per record with its group's material, the

@@ -63,7 +63,7 @@ ABI_SYMBOLS = [
     "rt_hip_render_frame_device", "rt_hip_render_tiles_device", "rt_hip_last_frame_rays", "rt_hip_photon_emit_device",
     "rt_hip_photon_set_device", "rt_hip_photon_set", "rt_hip_radiance_estimate_device", "rt_hip_radiance_estimate",
     "rt_hip_shade_results", "rt_hip_shade_results_device", "rt_hip_pack_tiles_device", "rt_hip_unpack_tiles_device",
-    "rt_hip_render_tiles_batch_device",
+    "rt_hip_render_tiles_batch_device", "rt_hip_live_frame_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device",
 ]
@@ -135,6 +135,7 @@ def load_library() -> C.CDLL:
     L.rt_hip_radiance_estimate_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_float, P]
     L.rt_hip_radiance_estimate.argtypes = [P, c_float_p, c_float_p, C.c_int, C.c_int, C.c_float, c_float_p]
     L.rt_hip_render_tiles_batch_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_live_frame_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.POINTER(C.c_int)]
     L.rt_hip_pack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
     L.rt_hip_unpack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
     L.rt_hip_shade_results.argtypes = [P, P, P, C.c_int, C.c_int, c_float_p, P]
@@ -326,6 +327,12 @@ class RtHip:
         self._ck(self.lib.rt_hip_render_tiles_batch_device(self.h, arr(*[_dptr(t) for t in d_pos_list]),
                                                            arr(*[_dptr(t) for t in d_nrm_list]), n, w, h, tile, rank, nranks,
                                                            arr(*[_dptr(t) for t in d_rgba_list])))
+
+    def live_frame_device(self, d_pos_rgb, d_nrm_rgba, w, h, interlace, phase, d_raypass_rgb8, d_rgba):
+        rays = C.c_int(0)
+        self._ck(self.lib.rt_hip_live_frame_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, interlace, phase,
+                                                   _dptr(d_raypass_rgb8), _dptr(d_rgba), C.byref(rays)))
+        return rays.value
 
     def pack_tiles_device(self, d_frame, w, h, tile, d_tile_list, ntiles, d_packed):
         self._ck(self.lib.rt_hip_pack_tiles_device(self.h, _dptr(d_frame), w, h, tile, _dptr(d_tile_list), ntiles, _dptr(d_packed)))

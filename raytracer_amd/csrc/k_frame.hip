@@ -737,7 +737,80 @@ __global__ __launch_bounds__(BLOCK) void k_node_points(const NodeGeo* __restrict
 	for (int k = 0; k < 3; ++k) { pos[3 * (size_t)i + k] = geo[i].V[k]; nrm[3 * (size_t)i + k] = geo[i].N[k]; }
 }
 
-// ---- live shading of hit records (a20) -----------------------------------------------------------
+// ---- live shading (a20) ----------------------------------------------------------------------------
+// mesh_fs.cpp:26-49: per light energy = color/255 * 50/(50+|L|^2); direct += energy*albedo*clamp(N.L)
+// + energy*scolor*pow(clamp(N.H), shininess), E = normalize(-pos); color = refl*reflection +
+// (1-refl)*direct.  Material and light colours / 255 (ras_rasterizer.cpp:184-188,232); at most
+// LIGHT_COUNT = 8 lights (mesh_fs.cpp:5); untextured (Texture::lookup is SURVEY 8f row 3).
+__device__ __forceinline__ f3 mesh_fs_color(const SceneView& sv, const MaterialRec& m, f3 pos, f3 nrm, f3 reflection)
+{
+	f3 albedo = div3(ld3(m.diffuse), 255.0f), scol = div3(ld3(m.specular), 255.0f);
+	f3 N = normalized3(nrm);
+	f3 E = normalized3(neg3(pos));
+	f3 direct = mk3(0, 0, 0);
+	const int nl = sv.num_lights < 8 ? sv.num_lights : 8;
+	for (int l = 0; l < nl; ++l) {
+		f3 L = ld3(sv.lights[l].position) - pos;
+		f3 energy = ld3(sv.lights[l].color) * (1.0f / 255);
+		float len = norm3(L);
+		energy = energy * (50.0f / (50.0f + len * len));
+		L = normalized3(L);
+		f3 H = normalized3(L + E);
+		float lambert = fminf(fmaxf(dot3(N, L), 0.0f), 1.0f);
+		float phong = powf(fminf(fmaxf(dot3(N, H), 0.0f), 1.0f), m.shininess);
+		direct.x = energy.x * albedo.x * lambert + energy.x * scol.x * phong + direct.x;
+		direct.y = energy.y * albedo.y * lambert + energy.y * scol.y * phong + direct.y;
+		direct.z = energy.z * albedo.z * lambert + energy.z * scol.z * phong + direct.z;
+	}
+	const float refl = m.reflectivity;
+	return mk3(refl * reflection.x + (1.0f - refl) * direct.x, refl * reflection.y + (1.0f - refl) * direct.y,
+	           refl * reflection.z + (1.0f - refl) * direct.z);
+}
+
+__device__ __forceinline__ uint8_t unorm8(float c) { return (uint8_t)rintf(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f); }
+
+// The raypass of Scene::draw (drawRayData, ras_rasterizer.cpp:619-669) without GL: every hit of the
+// selected texels is shaded at the HIT point with the hit's material and written, as RGB8, to the
+// texel the ray started from (the reference draws a point at Ray.origin, which projects back onto
+// that texel).  Misses draw nothing: the texel keeps what an earlier phase left there.
+__global__ __launch_bounds__(BLOCK) void k_live_raypass(SceneView sv, const Hit* __restrict__ hits,
+                                                        const int* __restrict__ texel, int n, uint8_t* __restrict__ raypass)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	HitInfo hi;
+	resolve_tri(sv, hits[i], hi, nullptr);
+	if (hi.material < 0) return;
+	f3 c = mesh_fs_color(sv, sv.materials[hi.material], ld3(hi.pos), ld3(hi.nrm), mk3(0, 0, 0));
+	uint8_t* px = raypass + 3 * (size_t)texel[i];
+	px[0] = unorm8(c.x); px[1] = unorm8(c.y); px[2] = unorm8(c.z);
+}
+
+// The forward pass (drawMeshes, :237-281; mesh_fs.cpp:46-47) from the G-buffer: the visible surface
+// shaded with its own material, reflection = the raypass texel (scale 1: texel centres, so the
+// GL_LINEAR fetch returns the texel), background = the clear colour 0.3.
+__global__ __launch_bounds__(BLOCK) void k_live_composite(SceneView sv, const float* __restrict__ pos_rgb,
+                                                          const float* __restrict__ nrm_rgba, int n,
+                                                          const uint8_t* __restrict__ raypass, uint8_t* __restrict__ rgba)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	float a = nrm_rgba[4 * (size_t)i + 3];
+	int mat = (a > 0.0f) ? ((int)a - 1) : -1;
+	if (mat >= sv.num_materials) mat = -1;
+	uint8_t* px = rgba + 4 * (size_t)i;
+	if (mat < 0) { px[0] = px[1] = px[2] = unorm8(0.3f); px[3] = 255; return; }
+	f3 N;
+	N.x = (float)((double)nrm_rgba[4 * (size_t)i + 0] * 2.0 - 1.0);
+	N.y = (float)((double)nrm_rgba[4 * (size_t)i + 1] * 2.0 - 1.0);
+	N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
+	const uint8_t* rp = raypass + 3 * (size_t)i;
+	f3 refl = mk3(rp[0] / 255.0f, rp[1] / 255.0f, rp[2] / 255.0f);
+	f3 c = mesh_fs_color(sv, sv.materials[mat], ld3(pos_rgb + 3 * (size_t)i), N, refl);
+	px[0] = unorm8(c.x); px[1] = unorm8(c.y); px[2] = unorm8(c.z); px[3] = 255;
+}
+
+// ---- live shading of hit records ---------------------------------------------------------------------
 // mesh_fs.cpp:26-49 at one hit record, as drawRayData draws it into the raypass target: the
 // record's group gives the material; reflection term = 0.  One lane per record.
 __global__ __launch_bounds__(BLOCK) void k_shade_results(SceneView sv, const rt_ray* __restrict__ rec, int n,
@@ -753,33 +826,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade_results(SceneView sv, const rt_
 		if (groups[mid].end > i) hi = mid; else lo = mid + 1;
 	}
 	const MaterialRec m = sv.materials[groups[lo].material];
-	f3 albedo = div3(ld3(m.diffuse), 255.0f), scol = div3(ld3(m.specular), 255.0f);
-	f3 pos = ld3(rec[i].position);
-	f3 N = normalized3(ld3(rec[i].normal));
-	f3 E = normalized3(neg3(pos));
-	f3 direct = mk3(0, 0, 0);
-	const int nl = sv.num_lights < 8 ? sv.num_lights : 8;  // LIGHT_COUNT (mesh_fs.cpp:5)
-	for (int l = 0; l < nl; ++l) {
-		f3 L = ld3(sv.lights[l].position) - pos;
-		f3 energy = ld3(sv.lights[l].color) * (1.0f / 255);
-		float len = norm3(L);
-		energy = energy * (50.0f / (50.0f + len * len));
-		L = normalized3(L);
-		f3 H = normalized3(L + E);
-		float lambert = fminf(fmaxf(dot3(N, L), 0.0f), 1.0f);
-		float phong = powf(fminf(fmaxf(dot3(N, H), 0.0f), 1.0f), m.shininess);
-		direct.x = energy.x * albedo.x * lambert + energy.x * scol.x * phong + direct.x;
-		direct.y = energy.y * albedo.y * lambert + energy.y * scol.y * phong + direct.y;
-		direct.z = energy.z * albedo.z * lambert + energy.z * scol.z * phong + direct.z;
-	}
-	const float refl = m.reflectivity;
-	f3 c = mk3(refl * 0.0f + (1.0f - refl) * direct.x, refl * 0.0f + (1.0f - refl) * direct.y,
-	           refl * 0.0f + (1.0f - refl) * direct.z);
+	f3 c = mesh_fs_color(sv, m, ld3(rec[i].position), ld3(rec[i].normal), mk3(0, 0, 0));
 	st3(rgb + 3 * (size_t)i, c);
 	if (rgb8) {  // GL UNORM8 conversion of the RGB8 raypass target
-		rgb8[3 * (size_t)i + 0] = (uint8_t)rintf(fminf(fmaxf(c.x, 0.0f), 1.0f) * 255.0f);
-		rgb8[3 * (size_t)i + 1] = (uint8_t)rintf(fminf(fmaxf(c.y, 0.0f), 1.0f) * 255.0f);
-		rgb8[3 * (size_t)i + 2] = (uint8_t)rintf(fminf(fmaxf(c.z, 0.0f), 1.0f) * 255.0f);
+		rgb8[3 * (size_t)i + 0] = unorm8(c.x);
+		rgb8[3 * (size_t)i + 1] = unorm8(c.y);
+		rgb8[3 * (size_t)i + 2] = unorm8(c.z);
 	}
 }
 
@@ -817,6 +869,40 @@ int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, in
 		hipLaunchKernelGGL(k_tiles_pack<false>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream,
 		                   (uint32_t*)d_frame, w, h, tile, d_tile_list, ntiles, (uint32_t*)d_packed);
 	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+// Scene::draw (data/scene.cpp:40-56) from the G-buffer on: select -> processRays' ray-gen and
+// closest hit -> raypass -> composite.  The hits are not grouped by material: that grouping only
+// exists to batch GL material binds (ras_rasterizer.cpp:653-662).
+int rt_live_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int interlace, int phase,
+                  uint8_t* d_raypass, uint8_t* d_rgba, int* out_rays)
+{
+	const int n = w * h;
+	*out_rays = 0;
+	RT_CHECK(ctx->d_in_a.reserve((size_t)n * 12));
+	RT_CHECK(ctx->d_in_b.reserve((size_t)n * 12));
+	RT_CHECK(ctx->d_ray_parent.reserve((size_t)n * 4));
+	int count = 0;
+	RT_CHECK(rt_gbuffer_select(ctx, d_nrm_rgba, d_pos_rgb, n, interlace, phase, ctx->d_in_a.as<float>(), ctx->d_in_b.as<float>(),
+	                           ctx->d_ray_parent.as<int>(), &count));
+	SceneView sv = rt_scene_view(ctx);
+	if (count > 0) {
+		RT_CHECK(ctx->d_org.reserve((size_t)count * 12));
+		RT_CHECK(ctx->d_dir.reserve((size_t)count * 12));
+		RT_CHECK(ctx->d_hits.reserve((size_t)count * sizeof(Hit)));
+		RT_CHECK(rt_launch_reflect_raygen(ctx, ctx->d_in_a.as<float>(), ctx->d_in_b.as<float>(), count, ctx->d_org.as<float>(),
+		                                  ctx->d_dir.as<float>()));
+		RT_CHECK(rt_launch_closest(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), count, ctx->d_hits.as<Hit>()));
+		hipLaunchKernelGGL(k_live_raypass, dim3(nblocks(count, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, ctx->d_hits.as<Hit>(),
+		                   ctx->d_ray_parent.as<int>(), count, d_raypass);
+	}
+	hipLaunchKernelGGL(k_live_composite, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, d_pos_rgb, d_nrm_rgba, n,
+	                   d_raypass, d_rgba);
+	RT_HIP_CHECK(hipGetLastError());
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	RT_CHECK(rt_collect_timing(ctx));
+	*out_rays = count;
 	return RT_HIP_OK;
 }
 

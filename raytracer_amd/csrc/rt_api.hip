@@ -744,6 +744,25 @@ int rt_hip_radiance_estimate(rt_hip_ctx* ctx, const float* pos, const float* nrm
 	return RT_HIP_OK;
 }
 
+// ---- the live (Gen-2) frame ---------------------------------------------------------------------------
+int rt_hip_live_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
+                             int height, int interlace, int phase, uint8_t* d_raypass_rgb8, uint8_t* d_rgba_out,
+                             int* out_rays)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_raypass_rgb8 || !d_rgba_out ||
+	    (interlace > 1 && (phase < 0 || phase >= interlace))) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	if (ctx->cfg.geometry != RT_HIP_TRIANGLES) { rt_set_error("the live frame needs triangle geometry"); return RT_HIP_ERR_STATE; }
+	if ((int64_t)width * height > (int64_t)1 << 28) { rt_set_error("frame larger than 2^28 texels"); return RT_HIP_ERR_LIMIT; }
+	int rays = 0;
+	RT_CHECK(rt_live_frame(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, interlace, phase, d_raypass_rgb8, d_rgba_out, &rays));
+	if (out_rays) *out_rays = rays;
+	return RT_HIP_OK;
+}
+
 // ---- packed tile exchange --------------------------------------------------------------------------
 static int check_tiles_args(const void* frame, int w, int h, int tile, const int* d_tile_list, int ntiles, const void* packed)
 {

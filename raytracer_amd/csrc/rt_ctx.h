@@ -185,6 +185,8 @@ int rt_gbuffer_select(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_p
                       int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* out_count);
 int rt_launch_shade_results(rt_hip_ctx* ctx, const rt_ray* d_rec, int n, const rt_result_offset* d_groups, int ngroups,
                             float* d_rgb, uint8_t* d_rgb8);
+int rt_live_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int interlace, int phase,
+                  uint8_t* d_raypass, uint8_t* d_rgba, int* out_rays);
 int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, int h, int tile, const int* d_tile_list,
                          int ntiles, uint8_t* d_packed);
 int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb);

@@ -67,4 +67,16 @@ dt = (time.perf_counter() - t0) / K
 out["process_gbuffer_device_ms"] = round(dt * 1e3, 3)
 out["process_gbuffer_device_mrays_s"] = round(pos.shape[0] / dt / 1e6, 1)
 out["process_gbuffer_groups"] = int(nmat)
+# the live (Gen-2) frame on the device: select -> ray-gen -> closest hit -> raypass -> composite
+d_rp = torch.full((W * H, 3), 255, dtype=torch.uint8, device="cuda")
+d_img = torch.zeros((W * H, 4), dtype=torch.uint8, device="cuda")
+for interlace in (1, 16):
+    for _ in range(2):
+        g2.live_frame_device(d_p, d_n, W, H, interlace, 0, d_rp, d_img)
+    t0 = time.perf_counter()
+    for k in range(K):
+        rays = g2.live_frame_device(d_p, d_n, W, H, interlace, k % interlace, d_rp, d_img)
+    dt = (time.perf_counter() - t0) / K
+    out["live_frame_interlace%d_ms" % interlace] = round(dt * 1e3, 3)
+    out["live_frame_interlace%d_rays" % interlace] = rays
 print(json.dumps(out))

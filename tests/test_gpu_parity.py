@@ -509,3 +509,68 @@ def test_render_tiles_batch_equals_single_frames(rt, oracle_cls, nranks, tile):
         # every pixel was written by exactly the rank that owns it (7 never survives: alpha is 0 or 255)
         np.testing.assert_array_equal(union[f], full[f])
     g.close()
+
+
+# ---- the live (Gen-2) frame: select -> processRays -> raypass -> composite ------------
+def _oracle_live_frame(orc, sc, nr, po, interlace, phase, raypass):
+    """Scene::draw from the G-buffer on, composed from the oracle's pieces (raypass updated in place)."""
+    from oracle.pyoracle import RAY_DTYPE
+    n = nr.shape[0]
+    sel_pos, sel_nrm, sel_idx = orc.gbuffer_select(nr, po, interlace, phase)
+    pr = orc.process_rays(sel_pos, sel_nrm)
+    tm = _tri_material(sc)
+    hit = pr["tidx"] != MISS
+    ray_mat = np.where(hit, tm[np.where(hit, pr["tidx"], 0)], -1)
+    start = 0
+    for m, end in zip(pr["offset_material"], pr["offset_end"]):
+        rays = np.nonzero(hit & (ray_mat == m))[0]                 # ascending input index inside a group
+        assert len(rays) == end - start
+        rgb = orc.shade_records(pr["records"][start:end], np.full(end - start, m, np.int32))
+        raypass[sel_idx[rays]] = np.rint(np.clip(rgb, 0, 1) * np.float32(255)).astype(np.uint8)
+        start = end
+    mid = nr[:, 3].astype(np.int32) - 1
+    cov = mid >= 0
+    rec = np.zeros(int(cov.sum()), RAY_DTYPE)
+    rec["position"] = po[cov]
+    rec["normal"] = (nr[cov, :3].astype(np.float64) * 2.0 - 1.0).astype(np.float32)
+    shaded = orc.shade_records(rec, mid[cov])                       # (1 - refl) * direct
+    refl = np.array([m.reflectivity for m in sc.materials], np.float32)[mid[cov]][:, None]
+    col = refl * (raypass[cov].astype(np.float32) / np.float32(255)) + shaded
+    out = np.zeros((n, 4), np.uint8)
+    out[:, :3] = 77                                                 # clear colour 0.3 -> rint(76.5) = 76 or 77, see below
+    out[:, 3] = 255
+    out[cov, :3] = np.rint(np.clip(col, 0, 1) * np.float32(255)).astype(np.uint8)
+    return out, int(sel_pos.shape[0]), cov
+
+
+@pytest.mark.parametrize("scene_fn", [scenes.cornell, lambda: scenes.atrium(2048)], ids=["cornell", "atrium2k"])
+def test_live_frame(rt, oracle_cls, scene_fn):
+    """16 interlace phases accumulate in the raypass image, then a full (interlace 1) frame.  Bar: 1/255 per
+    channel (powf differs between libm and the device library); at most 0.1 % of the texels may differ
+    more -- the exact-t ties where DACRT and the lowest-id rule pick different triangles of a shared edge."""
+    torch = _torch()
+    sc = scene_fn()
+    orc = oracle_cls(sc)
+    w, h = 96, 64
+    nr, po = orc.software_gbuffer(w, h)
+    g = rt.RtHip(sc, accel=2)
+    d_p, d_n = torch.from_numpy(po).cuda(), torch.from_numpy(nr).cuda()
+    d_rp = torch.full((w * h, 3), 255, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+    rp = np.full((w * h, 3), 255, np.uint8)
+    for interlace, phase in [(16, 3), (16, 4), (16, 0), (1, 0)]:
+        exp, nrays, cov = _oracle_live_frame(orc, sc, nr, po, interlace, phase, rp)
+        rays = g.live_frame_device(d_p, d_n, w, h, interlace, phase, d_rp, d_out)
+        assert rays == nrays > 0
+        got, got_rp = d_out.cpu().numpy(), d_rp.cpu().numpy()
+        bg = ~cov
+        assert (np.abs(got[bg, :3].astype(int) - 76.5) <= 0.5).all() and (got[:, 3] == 255).all()
+        d_rp_diff = np.abs(got_rp.astype(int) - rp.astype(int)).max(1)
+        d_img = np.abs(got[cov].astype(int) - exp[cov].astype(int)).max(1)
+        assert (d_rp_diff > 1).mean() <= 1e-3 and (d_img > 1).mean() <= 1e-3
+        assert exp[cov, :3].max() > 40
+    # after the full frame every reflective texel that hit something has left white behind
+    assert (rp != 255).any(1).sum() > 0.3 * cov.sum()
+    with pytest.raises(rt.RtHipError):
+        g.live_frame_device(d_p, d_n, w, h, 16, 16, d_rp, d_out)      # phase out of range
+    g.close()
