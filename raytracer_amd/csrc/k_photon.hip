@@ -210,7 +210,20 @@ __device__ __forceinline__ void for_each_neighbour(const GridDesc& gd, const uin
 		for (int y = y0; y <= y1; ++y) {
 			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
 			uint32_t s0 = cell_start[row + x0], s1 = cell_start[row + x1 + 1];
-			for (uint32_t s = s0; s < s1; ++s) {
+			// eight photons in flight per lane: the loads are independent of the loop body, and a
+			// lane walking its span one dependent 16-byte load at a time is latency-bound
+			uint32_t s = s0;
+			for (; s + 8 <= s1; s += 8) {
+				float4 q[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) q[k] = pos[s + k];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) {
+					f3 d = mk3(q[k].x, q[k].y, q[k].z) - P;
+					f(s + k, dot3(d, d));
+				}
+			}
+			for (; s < s1; ++s) {
 				float4 q = pos[s];
 				f3 d = mk3(q.x, q.y, q.z) - P;
 				f(s, dot3(d, d));
