@@ -141,6 +141,10 @@ def main():
         gb_n.append(d_n)
         gb_p.append(d_p)
     g.sync()
+    if os.environ.get("BENCH_DEBUG"):
+        cov = [int((n.view(-1, 4)[:, 3] > 0).sum().item()) for n in gb_n]
+        print("rank %d: build %s, covered texels per frame %s" % (rank, {k: build_stats[k] for k in ("num_tris", "num_nodes", "bvh_depth", "build_ms")}, cov),
+              file=sys.stderr, flush=True)
     tiles = [torch.zeros(npix * 4, dtype=torch.uint8, device=dev) for _ in range(nframes)]   # this rank's tiles of each frame
     frame = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)    # N > 1: frame `rank`, assembled from all ranks' tiles
     xchg = None
@@ -150,12 +154,19 @@ def main():
 
     def step():
         # this rank's tiles of all the step's frames in one wavefront (a batch of one at N = 1)
-        g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
-        rays = g.last_frame_rays()
-        if xchg:
+        if xchg and os.environ.get("BENCH_XCHG") == "pack":   # debugging aid: full-size tile images, then pack kernels
+            g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
+            rays = g.last_frame_rays()
             for f in range(nframes):
-                xchg.pack(f, tiles[f])    # my tiles of frame f -> the chunk that goes to rank f
-            xchg.exchange(frame)          # one all-to-all (RCCL), then frame `rank` is complete here
+                xchg.pack(f, tiles[f])
+            xchg.exchange(frame)
+        elif xchg:
+            xchg.render(gb_p, gb_n)       # ... written straight into the packed chunks: chunk f goes to rank f
+            rays = g.last_frame_rays()
+            xchg.exchange(frame)          # one all-to-all (RCCL) + one unpack kernel: frame `rank` is complete here
+        else:
+            g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
+            rays = g.last_frame_rays()
         return rays
 
     def fence():
@@ -175,6 +186,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     st = g.stats()
+    if os.environ.get("BENCH_DEBUG"):
+        print("rank %d: %d rays in %d steps, %.3f s; any %.3f ms / %d launches" % (rank, rays_rank, args.steps, elapsed, st["any_ms"], st["any_launches"]),
+              file=sys.stderr, flush=True)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     ry = torch.tensor([float(rays_rank)], dtype=torch.float64, device=red_dev)

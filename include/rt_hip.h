@@ -234,6 +234,17 @@ int rt_hip_render_tiles_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, con
 int rt_hip_render_tiles_batch_device(rt_hip_ctx* ctx, const float* const* d_gbuf_pos_rgb,
                                      const float* const* d_gbuf_nrm_rgba, int nframes, int width, int height,
                                      int tile, int rank, int nranks, uint8_t* const* d_rgba_out);
+/* The same batch with the output already PACKED for the exchange: d_packed_out[f] is the rank's chunk of
+ * frame f in the layout rt_hip_pack_tiles_device produces (own tiles in row-major tile order, each
+ * tile x tile pixels row-major; padding pixels of edge tiles are never written, so clear the chunks
+ * once).  Needs 1 < nranks <= 16 and tile % 8 == 0.  rt_hip_unpack_chunks_device is the receiving
+ * side: d_chunks holds nranks chunks of chunk_bytes each, chunk r = rank r's tiles of this frame;
+ * they are scattered into the full-size image (enqueued: rt_hip_sync() before reading it elsewhere). */
+int rt_hip_render_tiles_packed_device(rt_hip_ctx* ctx, const float* const* d_gbuf_pos_rgb,
+                                      const float* const* d_gbuf_nrm_rgba, int nframes, int width, int height,
+                                      int tile, int rank, int nranks, uint8_t* const* d_packed_out);
+int rt_hip_unpack_chunks_device(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int width, int height,
+                                int tile, int nranks, uint8_t* d_frame_rgba);
 /* Tile gather without moving empty pixels (collective #2): pack the tiles listed in
  * d_tile_list (ids ty * tiles_x + tx, ntiles of them; raytracer_amd/tiles.py: owned_tiles) from a
  * full-size RGBA8 frame into one contiguous buffer (tile after tile, tile x tile pixels row-major,

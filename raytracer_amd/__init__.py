@@ -63,7 +63,8 @@ ABI_SYMBOLS = [
     "rt_hip_render_frame_device", "rt_hip_render_tiles_device", "rt_hip_last_frame_rays", "rt_hip_photon_emit_device",
     "rt_hip_photon_set_device", "rt_hip_photon_set", "rt_hip_radiance_estimate_device", "rt_hip_radiance_estimate",
     "rt_hip_shade_results", "rt_hip_shade_results_device", "rt_hip_pack_tiles_device", "rt_hip_unpack_tiles_device",
-    "rt_hip_render_tiles_batch_device", "rt_hip_live_frame_device",
+    "rt_hip_render_tiles_batch_device", "rt_hip_live_frame_device", "rt_hip_render_tiles_packed_device",
+    "rt_hip_unpack_chunks_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device",
 ]
@@ -135,6 +136,8 @@ def load_library() -> C.CDLL:
     L.rt_hip_radiance_estimate_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_float, P]
     L.rt_hip_radiance_estimate.argtypes = [P, c_float_p, c_float_p, C.c_int, C.c_int, C.c_float, c_float_p]
     L.rt_hip_render_tiles_batch_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_render_tiles_packed_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_unpack_chunks_device.argtypes = [P, P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_live_frame_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.POINTER(C.c_int)]
     L.rt_hip_pack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
     L.rt_hip_unpack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
@@ -167,6 +170,26 @@ def _dptr(t):
     if isinstance(t, int):
         return C.c_void_p(t)
     return C.c_void_p(t.data_ptr())
+
+
+def _fence_torch():
+    """The library runs on a stream of its own.  A tensor handed to it may still have work pending on
+    torch's current stream (torch.zeros / torch.full / copy_ are asynchronous fills): drain that stream
+    first, or the fill can land AFTER the library's kernels have written the buffer."""
+    import sys
+    t = sys.modules.get("torch")
+    if t is not None and t.cuda.is_available() and t.cuda.is_initialized():
+        t.cuda.current_stream().synchronize()
+
+
+def _fenced(method):
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        _fence_torch()
+        return method(self, *args, **kwargs)
+    return wrapper
 
 
 class RtHip:
@@ -334,6 +357,16 @@ class RtHip:
                                                    _dptr(d_raypass_rgb8), _dptr(d_rgba), C.byref(rays)))
         return rays.value
 
+    def render_tiles_packed_device(self, d_pos_list, d_nrm_list, w, h, tile, rank, nranks, d_packed_list):
+        n = len(d_pos_list)
+        arr = C.c_void_p * n
+        self._ck(self.lib.rt_hip_render_tiles_packed_device(self.h, arr(*[_dptr(t) for t in d_pos_list]),
+                                                            arr(*[_dptr(t) for t in d_nrm_list]), n, w, h, tile, rank, nranks,
+                                                            arr(*[_dptr(t) for t in d_packed_list])))
+
+    def unpack_chunks_device(self, d_chunks, chunk_bytes, w, h, tile, nranks, d_frame):
+        self._ck(self.lib.rt_hip_unpack_chunks_device(self.h, _dptr(d_chunks), chunk_bytes, w, h, tile, nranks, _dptr(d_frame)))
+
     def pack_tiles_device(self, d_frame, w, h, tile, d_tile_list, ntiles, d_packed):
         self._ck(self.lib.rt_hip_pack_tiles_device(self.h, _dptr(d_frame), w, h, tile, _dptr(d_tile_list), ntiles, _dptr(d_packed)))
 
@@ -410,3 +443,8 @@ class RtHip:
         prims = np.zeros(nt, np.uint32)
         self._ck(self.lib.rt_hip_get_bvh(self.h, _p(nodes), nn, _p(prims, c_u32_p), nt))
         return nodes, prims
+
+
+# every entry that takes device pointers first waits for torch's pending work on those buffers
+for _name in [n for n in dir(RtHip) if n.endswith("_device")]:
+    setattr(RtHip, _name, _fenced(getattr(RtHip, _name)))

@@ -383,14 +383,17 @@ __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__
 // records are written once instead of written, re-read and re-written by three launches.
 // Level-0 node j of a frame -> pixel.  Without a tile list: 8x8 blocks of the whole frame.  With
 // one: the rank's own tiles one after the other, 8x8 blocks inside each tile (tile % 8 == 0).
-__device__ __forceinline__ int level0_pixel(const FrameSet& fs, int jj, int w, int h, int tile)
+// `slot` = where the pixel sits in the rank's packed chunk (tile after tile, row-major inside a tile).
+__device__ __forceinline__ int level0_pixel(const FrameSet& fs, int jj, int w, int h, int tile, int& slot)
 {
+	slot = 0;
 	if (!fs.tile_list) return tile8_pixel(jj, w, h);
 	const int t2 = tile * tile, tiles_x = (w + tile - 1) / tile, sub_x = tile >> 3;
-	const int id = fs.tile_list[jj / t2], r = jj % t2;
+	const int kt = jj / t2, id = fs.tile_list[kt], r = jj % t2;
 	const int sub = r >> 6, k = r & 63;
-	const int x = (id % tiles_x) * tile + ((sub % sub_x) << 3) + (k & 7);
-	const int y = (id / tiles_x) * tile + ((sub / sub_x) << 3) + (k >> 3);
+	const int lx = ((sub % sub_x) << 3) + (k & 7), ly = ((sub / sub_x) << 3) + (k >> 3);
+	const int x = (id % tiles_x) * tile + lx, y = (id / tiles_x) * tile + ly;
+	slot = kt * t2 + ly * tile + lx;
 	return (x < w && y < h) ? y * w + x : -1;
 }
 
@@ -406,7 +409,8 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
 	f3 P = mk3(0, 0, 0), R = mk3(0, 0, 0);
 	if (j < n0) {
 		const int f = j / fs.per_frame;
-		const int i = level0_pixel(fs, j - f * fs.per_frame, w, h, tile);
+		int slot;
+		const int i = level0_pixel(fs, j - f * fs.per_frame, w, h, tile, slot);
 		const float* __restrict__ pos_rgb = fs.pos[f];
 		const float* __restrict__ nrm_rgba = fs.nrm[f];
 		int mat = -2;  // -2: padding of a partial tile, or not this rank's texel: leave the pixel alone
@@ -426,7 +430,9 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
 		const f3 I = active ? normalized3(P) : mk3(0, 0, 0);
 		NodeGeo g;
 		st3(g.V, P); st3(g.N, N); st3(g.I, I);
-		g.parent = i < 0 ? -1 : f * (w * h) + i; g.material = mat; g.branch = 0;
+		// where k_combine writes this node's pixel: frame f's image, or (packed) the rank's chunk of frame f
+		g.parent = i < 0 ? -1 : (fs.packed ? f * fs.per_frame + slot : f * (w * h) + i);
+		g.material = mat; g.branch = 0;
 		geo[j] = g;
 		NodeShade s;
 		s.pad0 = s.pad1 = s.pad2 = 0;
@@ -854,9 +860,63 @@ __global__ __launch_bounds__(BLOCK) void k_tiles_pack(uint32_t* __restrict__ fra
 	else if (inside) frame[(size_t)y * w + x] = packed[p];
 }
 
+// All ranks' chunks of one received step into one frame: chunk r holds rank r's tiles.
+struct ChunkLists {
+	int offset[RT_MAX_BATCH + 1];  // rank r's tile ids are all_tiles[offset[r] .. offset[r + 1])
+};
+__global__ __launch_bounds__(BLOCK) void k_unpack_chunks(const uint32_t* __restrict__ chunks, int64_t chunk_pixels,
+                                                         int nranks, ChunkLists cl, const int* __restrict__ all_tiles,
+                                                         int w, int h, int tile, uint32_t* __restrict__ frame)
+{
+	const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (p >= chunk_pixels * nranks) return;
+	const int r = (int)(p / chunk_pixels);
+	const int64_t local = p - (int64_t)r * chunk_pixels;
+	const int t2 = tile * tile, kt = (int)(local / t2);
+	if (kt >= cl.offset[r + 1] - cl.offset[r]) return;  // padding at the end of a short chunk
+	const int tiles_x = (w + tile - 1) / tile;
+	const int id = all_tiles[cl.offset[r] + kt], k = (int)(local % t2);
+	const int x = (id % tiles_x) * tile + k % tile, y = (id / tiles_x) * tile + k / tile;
+	if (x < w && y < h) frame[(size_t)y * w + x] = chunks[p];
+}
+
 }  // namespace
 
 // ================================================================================================
+int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int w, int h, int tile, int nranks,
+                     uint8_t* d_frame)
+{
+	const int key[4] = {w, h, tile, nranks};
+	const int tiles_x = (w + tile - 1) / tile, tiles_y = (h + tile - 1) / tile;
+	if (memcmp(key, ctx->all_tiles_key, sizeof(key)) != 0 || !ctx->d_all_tiles.p) {
+		std::vector<int> ids;
+		for (int r = 0; r < nranks; ++r) {
+			ctx->all_tiles_offset[r] = (int)ids.size();
+			for (int ty = 0; ty < tiles_y; ++ty)
+				for (int tx = 0; tx < tiles_x; ++tx)
+					if ((tx + ty) % nranks == r) ids.push_back(ty * tiles_x + tx);
+		}
+		ctx->all_tiles_offset[nranks] = (int)ids.size();
+		RT_CHECK(ctx->d_all_tiles.reserve(std::max<size_t>(ids.size(), 1) * sizeof(int)));
+		RT_HIP_CHECK(hipMemcpy(ctx->d_all_tiles.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+		memcpy(ctx->all_tiles_key, key, sizeof(key));
+	}
+	ChunkLists cl;
+	int most = 0;
+	for (int r = 0; r <= nranks; ++r) cl.offset[r] = ctx->all_tiles_offset[r];
+	for (int r = 0; r < nranks; ++r) most = std::max(most, cl.offset[r + 1] - cl.offset[r]);
+	const int64_t chunk_pixels = chunk_bytes / 4;
+	if (chunk_pixels < (int64_t)most * tile * tile) {
+		rt_set_error("chunk of %lld bytes cannot hold %d tiles of %d x %d RGBA8 pixels", (long long)chunk_bytes, most, tile, tile);
+		return RT_HIP_ERR_ARG;
+	}
+	const int64_t n = chunk_pixels * nranks;
+	hipLaunchKernelGGL(k_unpack_chunks, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream,
+	                   (const uint32_t*)d_chunks, chunk_pixels, nranks, cl, ctx->d_all_tiles.as<int>(), w, h, tile, (uint32_t*)d_frame);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
 int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, int h, int tile, const int* d_tile_list,
                          int ntiles, uint8_t* d_packed)
 {
@@ -1129,12 +1189,15 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	hipStream_t st = ctx->stream;
 	SceneView sv = rt_scene_view(ctx);
 	const int bounces = ctx->cfg.bounces;
-	fs.tile_list = nullptr; fs.ntiles = 0;
+	const int packed = fs.packed;
+	fs.tile_list = nullptr; fs.ntiles = 0; fs.packed = 0;
 	fs.per_frame = tile8_count(w, h);
 	if (nranks > 1 && tile % 8 == 0) {
 		RT_CHECK(owned_tile_list(ctx, w, h, tile, rank, nranks, &fs.tile_list, &fs.ntiles));
 		fs.per_frame = fs.ntiles * tile * tile;
+		fs.packed = packed;
 	}
+	if (packed && !fs.packed) { rt_set_error("packed tile output needs nranks > 1 and a tile size that is a multiple of 8"); return RT_HIP_ERR_ARG; }
 	if ((int64_t)fs.per_frame * fs.nframes > FRAME_LEVEL_CAP) return RT_HIP_OK;
 	const int n0 = fs.per_frame * fs.nframes;
 	if (n0 == 0) { *declined = false; return RT_HIP_OK; }  // this rank owns no tile
@@ -1250,7 +1313,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + off[L - 1] : nullptr;
 		const unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
 		hipLaunchKernelGGL(k_combine, dim3(nblocks((int)cap[L], BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, (int)cap[L], n_ptr, L,
-		                   pshade, fs, w * h, (float*)nullptr, 1, occl);
+		                   pshade, fs, fs.packed ? fs.per_frame : w * h, (float*)nullptr, 1, occl);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	int* h_fc = (int*)ctx->h_small;  // 4 KiB pinned; nfc <= 80 ints
@@ -1287,7 +1350,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
                              int rank, int nranks, uint8_t* d_rgba);
 
 int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
-                     int h, int tile, int rank, int nranks, uint8_t* const* d_rgba)
+                     int h, int tile, int rank, int nranks, uint8_t* const* d_rgba, int packed)
 {
 	ctx->last_frame_rays = 0;
 	if (w <= 0 || h <= 0 || nframes <= 0 || ctx->cfg.bounces <= 0) return RT_HIP_OK;
@@ -1303,16 +1366,34 @@ int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float
 		FrameSet fs;
 		memset(&fs, 0, sizeof(fs));
 		fs.nframes = nframes;
+		fs.packed = packed;
 		for (int f = 0; f < nframes; ++f) { fs.pos[f] = d_pos_rgb[f]; fs.nrm[f] = d_nrm_rgba[f]; fs.rgba[f] = d_rgba[f]; }
 		bool overflowed = false, declined = false;
 		RT_CHECK(render_frame_async(ctx, fs, w, h, tile, rank, nranks, &overflowed, &declined));
 		if (!overflowed && !declined) return RT_HIP_OK;
+		// exceptional, and an order of magnitude slower for split frames: say so once per context
+		if (!ctx->warned_fallback) {
+			ctx->warned_fallback = true;
+			fprintf(stderr, "librt_hip: frame batch (%d x %dx%d, rank %d/%d) %s; rendering frame by frame with host-sized levels\n",
+			        nframes, w, h, rank, nranks, overflowed ? "overflowed a level's bound" : "is too large to size by bounds");
+		}
 	}
-	// frame by frame, every level sized on the host
+	// frame by frame, every level sized on the host (full-size image, then packed if asked for)
 	int64_t rays = 0;
 	for (int f = 0; f < nframes; ++f) {
-		RT_CHECK(render_frame_sync(ctx, d_pos_rgb[f], d_nrm_rgba[f], w, h, tile, rank, nranks, d_rgba[f]));
+		uint8_t* target = d_rgba[f];
+		if (packed) {
+			RT_CHECK(ctx->d_offsets.reserve((size_t)w * h * 4));
+			target = ctx->d_offsets.as<uint8_t>();
+		}
+		RT_CHECK(render_frame_sync(ctx, d_pos_rgb[f], d_nrm_rgba[f], w, h, tile, rank, nranks, target));
 		rays += ctx->last_frame_rays;
+		if (packed) {
+			const int* list; int nt;
+			RT_CHECK(owned_tile_list(ctx, w, h, tile, rank, nranks, &list, &nt));
+			RT_CHECK(rt_launch_tiles_pack(ctx, true, target, w, h, tile, list, nt, d_rgba[f]));
+			RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		}
 	}
 	ctx->last_frame_rays = rays;
 	return RT_HIP_OK;

@@ -90,6 +90,7 @@ struct FrameSet {
 	int per_frame;         // level-0 nodes per frame
 	const int* tile_list;  // owned tile ids (ty * tiles_x + tx), or nullptr: every 8x8 block of the frame
 	int ntiles;
+	int packed;            // 1: rgba[f] is the PACKED chunk of the rank's tiles (tile after tile, row-major inside), not a frame
 };
 
 struct rt_hip_ctx {
@@ -102,6 +103,10 @@ struct rt_hip_ctx {
 	DevBuf d_census, d_spill, d_tile_list;
 	int tile_key[5] = {0, 0, 0, 0, 0};                            // (w, h, tile, rank, nranks) of d_tile_list
 	int tile_count = 0;
+	bool warned_fallback = false;
+	DevBuf d_all_tiles;                                           // every rank's tile list, concatenated (unpack of a received step)
+	int all_tiles_key[4] = {0, 0, 0, 0};                          // (w, h, tile, nranks)
+	int all_tiles_offset[RT_MAX_BATCH + 1] = {};
 	int max_trace_threads = 0;  // grid cap of the trace kernels = RT_TRACE_OVERSUB x resident-thread capacity
 
 	std::vector<HostMesh> meshes;
@@ -193,7 +198,9 @@ int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgb
 int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
                     int rank, int nranks, uint8_t* d_rgba);
 int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
-                     int h, int tile, int rank, int nranks, uint8_t* const* d_rgba);
+                     int h, int tile, int rank, int nranks, uint8_t* const* d_rgba, int packed = 0);
+int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int w, int h, int tile, int nranks,
+                     uint8_t* d_frame);
 
 // ---- k_photon.hip --------------------------------------------------------------------------------
 int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count, float* d_out, int64_t capacity,

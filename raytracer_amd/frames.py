@@ -1,9 +1,10 @@
 """Host side of the tile gather (collective #2).
 
 With N GPUs a step renders N frames; every frame is split over the ranks by interleaved tiles
-(`tiles.tile_owner`), and frame f is assembled on rank f.  Each rank packs its tiles of frame f into
-one contiguous chunk (`rt_hip_pack_tiles_device`), one all-to-all moves chunk f to rank f, and the
-receiver scatters the N chunks into its frame (`rt_hip_unpack_tiles_device`).  Only owned pixels
+(`tiles.tile_owner`), and frame f is assembled on rank f.  Each rank shades its tiles of frame f straight into one
+contiguous chunk (`rt_hip_render_tiles_packed_device`; `rt_hip_pack_tiles_device` does the same from a
+full-size image), one all-to-all moves chunk f to rank f, and the receiver scatters the N chunks
+into its frame with one kernel (`rt_hip_unpack_chunks_device`).  Only owned pixels
 travel: (N-1)/N of one frame per rank and step (7.3 MB at 1080p, N = 8), not N full frames as an
 all-reduce of sparse images would move.  RCCL over xGMI on the GPU box, gloo in the CPU tests (where
 `tiles.pack_tiles` / `unpack_tiles` stand in for the kernels).
@@ -16,24 +17,35 @@ from .tiles import max_owned_tiles, owned_tiles
 
 
 class TileExchange:
+    """step(): this rank's tiles of the N frames, rendered straight into the send chunks (one wavefront,
+    packed layout), one all-to-all, one unpack kernel: frame `rank` is then complete in `d_frame_rgba`."""
+
     def __init__(self, ctx, width, height, tile, rank, world, device, group=None):
         self.ctx, self.w, self.h, self.tile, self.rank, self.world, self.group = ctx, width, height, tile, rank, world, group
         lists = [owned_tiles(width, height, tile, r, world) for r in range(world)]
         self.ntiles = [int(len(l)) for l in lists]
         self.chunk = max_owned_tiles(width, height, tile, world) * tile * tile * 4   # bytes, equal splits
         self.d_lists = [torch.from_numpy(np.ascontiguousarray(l)).to(device) for l in lists]
-        self.send = torch.zeros(world * self.chunk, dtype=torch.uint8, device=device)
+        self.send = torch.zeros(world * self.chunk, dtype=torch.uint8, device=device)   # zero once: padding is never written
         self.recv = torch.zeros(world * self.chunk, dtype=torch.uint8, device=device)
 
+    def chunks(self):
+        c = self.chunk
+        return [self.send[f * c:(f + 1) * c] for f in range(self.world)]
+
+    def render(self, d_pos_list, d_nrm_list):
+        """Shade this rank's tiles of every frame of the step into the send chunks (chunk f -> rank f)."""
+        self.ctx.render_tiles_packed_device(d_pos_list, d_nrm_list, self.w, self.h, self.tile, self.rank, self.world, self.chunks())
+
     def pack(self, frame_index, d_tiles_rgba):
-        """Queue this rank's tiles of frame `frame_index` (full-size image, own tiles filled in)."""
+        """Alternative to render(): pack this rank's tiles of a full-size image into chunk `frame_index`."""
         c = self.chunk
         self.ctx.pack_tiles_device(d_tiles_rgba, self.w, self.h, self.tile, self.d_lists[self.rank], self.ntiles[self.rank],
                                    self.send[frame_index * c:(frame_index + 1) * c])
 
     def exchange(self, d_frame_rgba):
         """All-to-all of the packed chunks, then assemble frame `rank` in d_frame_rgba."""
-        self.ctx.sync()                                           # packs done before the collective reads them
+        self.ctx.sync()                                           # chunks complete before the collective reads them
         if dist.get_backend(self.group) == "gloo":                # rehearsal on a box without RCCL peers: stage through the host
             recv = torch.zeros(self.recv.shape, dtype=torch.uint8)
             dist.all_to_all_single(recv, self.send.cpu(), group=self.group)
@@ -41,8 +53,5 @@ class TileExchange:
         else:
             dist.all_to_all_single(self.recv, self.send, group=self.group)
         torch.cuda.current_stream().synchronize()                 # chunks landed before the context's stream reads them
-        c = self.chunk
-        for r in range(self.world):
-            self.ctx.unpack_tiles_device(self.recv[r * c:(r + 1) * c], self.w, self.h, self.tile, self.d_lists[r], self.ntiles[r],
-                                         d_frame_rgba)
+        self.ctx.unpack_chunks_device(self.recv, self.chunk, self.w, self.h, self.tile, self.world, d_frame_rgba)
         self.ctx.sync()

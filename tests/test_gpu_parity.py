@@ -574,3 +574,47 @@ def test_live_frame(rt, oracle_cls, scene_fn):
     with pytest.raises(rt.RtHipError):
         g.live_frame_device(d_p, d_n, w, h, 16, 16, d_rp, d_out)      # phase out of range
     g.close()
+
+
+def test_packed_render_and_unpack_chunks(rt, oracle_cls):
+    """The exchange path of an N-GPU step on one GPU: every virtual rank renders its tiles of 3 frames
+    straight into packed chunks; the chunks must equal pack_tiles() of the full frames, and
+    rt_hip_unpack_chunks_device on the chunks a rank would RECEIVE for frame f must rebuild frame f."""
+    torch = _torch()
+    from raytracer_amd.tiles import max_owned_tiles, owned_tiles, pack_tiles
+    sc = scenes.cornell()
+    orc = oracle_cls(sc)
+    w, h, tile, nranks = 100, 75, 16, 3
+    g = rt.RtHip(sc, semantics="array", do_shadows=1, shadow_t_max=1.0)
+    gb, full = [], []
+    for f in range(3):
+        nr, po = orc.software_gbuffer(w, h, fov=sc.fov - 0.04 * f)
+        d_p, d_n = torch.from_numpy(po).cuda(), torch.from_numpy(nr).cuda()
+        gb.append((d_p, d_n))
+        img = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+        g.render_frame_device(d_p, d_n, w, h, img)
+        full.append(img.cpu().numpy().reshape(-1, 4))
+    chunk = max_owned_tiles(w, h, tile, nranks) * tile * tile * 4
+    sent = []                                            # sent[r][f]: rank r's chunk of frame f
+    for r in range(nranks):
+        send = torch.zeros(3 * chunk, dtype=torch.uint8, device="cuda")
+        g.render_tiles_packed_device([p for p, _ in gb], [n for _, n in gb], w, h, tile, r, nranks,
+                                     [send[f * chunk:(f + 1) * chunk] for f in range(3)])
+        host = send.cpu().numpy().reshape(3, chunk)
+        ids = owned_tiles(w, h, tile, r, nranks)
+        for f in range(3):
+            want = pack_tiles(full[f], w, h, tile, ids).reshape(-1)
+            np.testing.assert_array_equal(host[f][: want.shape[0]], want)
+            assert (host[f][want.shape[0]:] == 0).all()
+        sent.append(host)
+    for f in range(3):                                   # what rank f receives: chunk f of every rank
+        recv = torch.from_numpy(np.concatenate([sent[r][f] for r in range(nranks)])).cuda()
+        out = torch.full((w * h, 4), 9, dtype=torch.uint8, device="cuda")
+        g.unpack_chunks_device(recv, chunk, w, h, tile, nranks, out)
+        g.sync()
+        np.testing.assert_array_equal(out.cpu().numpy(), full[f])
+    with pytest.raises(rt.RtHipError):
+        g.render_tiles_packed_device([gb[0][0]], [gb[0][1]], w, h, 20, 0, nranks, [recv])      # tile not a multiple of 8
+    with pytest.raises(rt.RtHipError):
+        g.unpack_chunks_device(recv, 64, w, h, tile, nranks, out)                             # chunk too small
+    g.close()
