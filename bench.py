@@ -152,6 +152,8 @@ def main():
         from raytracer_amd.frames import TileExchange
         xchg = TileExchange(g, W, H, 64, rank, world, dev)
 
+    render_batch = rt.RtHip.render_tiles_batch_device.__wrapped__
+
     def step():
         # this rank's tiles of all the step's frames in one wavefront (a batch of one at N = 1)
         if xchg and os.environ.get("BENCH_XCHG") == "pack":   # debugging aid: full-size tile images, then pack kernels
@@ -165,7 +167,9 @@ def main():
             rays = g.last_frame_rays()
             xchg.exchange(frame)          # one all-to-all (RCCL) + one unpack kernel: frame `rank` is complete here
         else:
-            g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
+            # the binding's un-fenced entry: the G-buffers were complete before the loop and the call itself
+            # returns only after its last kernel, so the per-call torch-stream drain has nothing to wait for
+            render_batch(g, gb_p, gb_n, W, H, 64, rank, world, tiles)
             rays = g.last_frame_rays()
         return rays
 

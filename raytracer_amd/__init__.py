@@ -188,7 +188,9 @@ def _fenced(method):
     @functools.wraps(method)
     def wrapper(self, *args, **kwargs):
         _fence_torch()
-        return method(self, *args, **kwargs)
+        out = method(self, *args, **kwargs)
+        self.sync()   # and the other way round: the outputs are complete before torch (or a collective) reads them
+        return out
     return wrapper
 
 

@@ -35,7 +35,9 @@ class TileExchange:
 
     def render(self, d_pos_list, d_nrm_list):
         """Shade this rank's tiles of every frame of the step into the send chunks (chunk f -> rank f)."""
-        self.ctx.render_tiles_packed_device(d_pos_list, d_nrm_list, self.w, self.h, self.tile, self.rank, self.world, self.chunks())
+        # un-fenced entry: the call returns after its last kernel, and exchange() orders the streams around the collective
+        type(self.ctx).render_tiles_packed_device.__wrapped__(self.ctx, d_pos_list, d_nrm_list, self.w, self.h, self.tile, self.rank,
+                                                              self.world, self.chunks())
 
     def pack(self, frame_index, d_tiles_rgba):
         """Alternative to render(): pack this rank's tiles of a full-size image into chunk `frame_index`."""
@@ -45,7 +47,7 @@ class TileExchange:
 
     def exchange(self, d_frame_rgba):
         """All-to-all of the packed chunks, then assemble frame `rank` in d_frame_rgba."""
-        self.ctx.sync()                                           # chunks complete before the collective reads them
+        torch.cuda.current_stream().synchronize()                 # nothing of torch's pending on send / recv
         if dist.get_backend(self.group) == "gloo":                # rehearsal on a box without RCCL peers: stage through the host
             recv = torch.zeros(self.recv.shape, dtype=torch.uint8)
             dist.all_to_all_single(recv, self.send.cpu(), group=self.group)
@@ -54,4 +56,3 @@ class TileExchange:
             dist.all_to_all_single(self.recv, self.send, group=self.group)
         torch.cuda.current_stream().synchronize()                 # chunks landed before the context's stream reads them
         self.ctx.unpack_chunks_device(self.recv, self.chunk, self.w, self.h, self.tile, self.world, d_frame_rgba)
-        self.ctx.sync()
