@@ -259,6 +259,11 @@ class RtHip:
     def update(self):
         self._ck(self.lib.rt_hip_update(self.h))
 
+    def set_model_mat(self, mesh_id, model_colmajor16):
+        """Mesh::model_mat of one mesh (column-major 4x4); takes effect at the next update()."""
+        m = np.ascontiguousarray(model_colmajor16, dtype=np.float32).reshape(16)
+        self._ck(self.lib.rt_hip_set_model_mat(self.h, int(mesh_id), _p(m)))
+
     def set_config(self, **kw):
         for k, v in kw.items():
             setattr(self.cfg, k, v)

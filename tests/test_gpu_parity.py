@@ -618,3 +618,30 @@ def test_packed_render_and_unpack_chunks(rt, oracle_cls):
     with pytest.raises(rt.RtHipError):
         g.unpack_chunks_device(recv, 64, w, h, tile, nranks, out)                             # chunk too small
     g.close()
+
+
+def test_scene_update_equals_fresh_build(rt, oracle_cls):
+    """processRays re-reads Mesh::model_mat every frame (rt_raytracer.cpp:467): after set_model_mat + update
+    the context must behave like one built from the moved scene, and like the oracle."""
+    sc = scenes.atrium(2048)
+    g = rt.RtHip(sc)
+    orc0 = oracle_cls(sc)
+    pos, nrm, _ = _gbuf_samples(orc0, 96, 64)
+    for k in range(3):
+        a = 0.07 * (k + 1)
+        M = np.eye(4, dtype=np.float32)
+        M[0, 0], M[0, 2], M[2, 0], M[2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+        M[1, 3] = 0.2 * k
+        sc.meshes[2].model = M
+        g.set_model_mat(2, sc.meshes[2].model_colmajor())
+        g.update()
+        fresh = rt.RtHip(sc)
+        a_, b_ = g.process_rays(pos, nrm), fresh.process_rays(pos, nrm)
+        fresh.close()
+        np.testing.assert_array_equal(a_["tidx"], b_["tidx"])
+        assert_bits_equal(a_["t"], b_["t"], "t")
+        o = oracle_cls(sc).process_rays(pos, nrm)
+        hit = o["tidx"] != MISS
+        np.testing.assert_array_equal(hit, a_["tidx"] != MISS)
+        assert_bits_equal(o["t"][hit], a_["t"][hit], "t vs oracle")
+    g.close()
