@@ -151,6 +151,14 @@ int rt_hip_set_config(rt_hip_ctx* ctx, const rt_hip_config* cfg);   /* shading/p
 /* Scene::materials / Scene::lights (data/scene.h:8-10).  Material ids are indices into this table. */
 int rt_hip_set_materials(rt_hip_ctx* ctx, const rt_material* materials, int n);
 int rt_hip_set_lights(rt_hip_ctx* ctx, const rt_light* lights, int n);
+/* Material::texture = new Texture(path) (data/data.h:25, data/loader.cpp:110-121) with the decoded
+ * image handed in: RGBA8 (the order Texture::Texture converts to, data/data.cpp:19-26), row 0 = the
+ * bottom scanline (FreeImage_GetBits order, also what glTexImage2D receives, ras_rasterizer.cpp:132).
+ * The image is copied.  rgba == NULL removes the texture.  rt_hip_set_materials drops all textures.
+ * A textured material's diffuse colour becomes Texture::lookup(u, v) (data/data.cpp:35-57, 0..255)
+ * in shade() (rt_raytracer.cpp:93-95) and texture2D(GL_NEAREST, repeat) / 255 in the live shading
+ * (mesh_fs.cpp:29-30).  Untextured scenes take none of these paths. */
+int rt_hip_set_texture(rt_hip_ctx* ctx, int material_id, const uint8_t* rgba, int width, int height);
 /* IAccel::addMesh / RayTracer::addMesh (rt_iaccel.h:7, rt_raytracer.cpp:69).  Geometry is copied.
  * model_mat16 is column-major (Eigen default).  position3 is Mesh::position (the sphere centre
  * for RT_HIP_SPHERES, rt_accel_spheres.cpp:27-31).  Returns the mesh id (>= 0). */
@@ -213,6 +221,17 @@ int rt_hip_gbuffer_select_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const
  * position; prepass_fs.cpp:11-13, ras_rasterizer.cpp:293,301); alpha = material id + 1, 0 = empty. */
 int rt_hip_render_gbuffer_device(rt_hip_ctx* ctx, float fov, int width, int height, float* d_nrm_rgba,
                                  float* d_pos_rgb);
+/* The same plus the interpolated texture coordinate of the visible surface (width*height x 2; the
+ * rasterizer's outCoord varying, mesh_vs/mesh_fs.cpp:29), (0,0) where nothing is visible. */
+int rt_hip_render_gbuffer_uv_device(rt_hip_ctx* ctx, float fov, int width, int height, float* d_nrm_rgba,
+                                    float* d_pos_rgb, float* d_uv);
+/* Texture coordinates of the G-buffer texels for the frame calls that follow (render_frame,
+ * render_tiles*, live_frame): d_uv[f] = width*height x 2 floats of frame f of a batch, in device
+ * memory that stays valid until replaced.  nframes = 0 clears: level-0 lookups then use (0,0), a
+ * Ray record's zeroed texcoord.  Only read when a material of the scene is textured.  The G-buffer of
+ * the reference carries no texcoords (Ray::texcoord is never set by getRayTraceData,
+ * ras_rasterizer.cpp:509-536); the forward pass gets them from the rasterizer's interpolation. */
+int rt_hip_set_frame_texcoords_device(rt_hip_ctx* ctx, const float* const* d_uv, int nframes);
 
 /* ---- full frame: G-buffer in, RGBA8 out ---------------------------------------------------- */
 /* Gen-1 shade() (rt_raytracer.cpp:75-160) evaluated at every G-buffer texel with alpha > 0

@@ -88,6 +88,9 @@ class Oracle:
         L.orc_gbuffer_select.argtypes = [C.c_int, c_float_p, c_float_p, C.c_int, C.c_int, c_float_p, c_float_p, c_int_p]
         L.orc_render_texels.argtypes = [C.c_void_p, C.POINTER(ShadeConfig), C.c_int, c_float_p, c_float_p, c_int_p,
                                         c_u8_p, c_float_p, C.POINTER(C.c_int64)]
+        L.orc_render_texels_uv.argtypes = [C.c_void_p, C.POINTER(ShadeConfig), C.c_int, c_float_p, c_float_p, c_float_p,
+                                           c_int_p, c_u8_p, c_float_p, C.POINTER(C.c_int64)]
+        L.orc_set_texture.argtypes = [C.c_void_p, C.c_int, c_u8_p, C.c_int, C.c_int]
         L.orc_shade_records.argtypes = [C.c_void_p, C.c_int, C.c_void_p, c_int_p, c_float_p]
         L.orc_photon_generate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
         L.orc_photon_generate_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int64]
@@ -112,6 +115,11 @@ class Oracle:
         L = self.lib
         for m in scene.materials:
             L.orc_add_material(self.h, _p(_f(m.diffuse)), _p(_f(m.specular)), m.shininess, m.reflectivity, m.alpha, m.ior)
+        for i, m in enumerate(scene.materials):
+            tex = getattr(m, "texture", None)
+            if tex is not None:                                      # (h, w, 4) u8, row 0 = bottom scanline
+                tex = np.ascontiguousarray(tex, dtype=np.uint8)
+                L.orc_set_texture(self.h, i, _p(tex, c_u8_p), tex.shape[1], tex.shape[0])
         for me in scene.meshes:
             L.orc_add_mesh(self.h, _p(me.verts), _p(me.normals), _p(me.texcoords), me.verts.shape[0],
                            _p(me.faces, c_u32_p), me.faces.shape[0], _p(me.model_colmajor()), me.material,
@@ -230,7 +238,7 @@ class Oracle:
         c = self.lib.orc_gbuffer_select(n, _p(nrm_rgba), _p(pos_rgb), interlace, phase, _p(op), _p(on), _p(oi, c_int_p))
         return op[:c].copy(), on[:c].copy(), oi[:c].copy()
 
-    def software_gbuffer(self, w, h, fov=None):
+    def software_gbuffer(self, w, h, fov=None, with_uv=False):
         """Primary visibility by camera rays (Camera::getScreenRays geometry) against the object-space
         triangles with AccelArray semantics, then the reference's G-buffer encodings.  alpha =
         material id + 1 (0 = background).  Returns (nrm_rgba, pos_rgb)."""
@@ -241,20 +249,24 @@ class Oracle:
         alpha = np.where(r["hit"] > 0, r["material"] + 1, 0).astype(np.float32)
         nrm = np.where(r["hit"][:, None] > 0, r["records"]["normal"], np.array([0, 0, 1], np.float32))
         pos = np.where(r["hit"][:, None] > 0, r["records"]["position"], 0).astype(np.float32)
+        if with_uv:                                                  # the rasterizer's interpolated outCoord
+            uv = np.where(r["hit"][:, None] > 0, r["records"]["texcoord"], 0).astype(np.float32)
+            return self.gbuffer_encode(nrm, pos, alpha) + (np.ascontiguousarray(uv),)
         return self.gbuffer_encode(nrm, pos, alpha)
 
     # ---- shading --------------------------------------------------------------------------
     def render_texels(self, pos, nrm, material_id, bounces=2, do_shadows=0, use_photon_map=0, photon_estimate=100,
-                      photon_radius=1.0, geometry=0, shadow_t_max=0.0):
+                      photon_radius=1.0, geometry=0, shadow_t_max=0.0, uv=None):
         pos, nrm = _f(pos), _f(nrm)
+        uv = None if uv is None else _f(uv)
         mid = np.ascontiguousarray(material_id, dtype=np.int32)
         n = pos.shape[0]
         cfg = ShadeConfig(bounces, do_shadows, use_photon_map, photon_estimate, photon_radius, geometry, shadow_t_max)
         rgba = np.zeros((n, 4), np.uint8)
         rgbf = np.zeros((n, 3), np.float32)
         rays = C.c_int64(0)
-        self.lib.orc_render_texels(self.h, C.byref(cfg), n, _p(pos), _p(nrm), _p(mid, c_int_p), _p(rgba, c_u8_p),
-                                   _p(rgbf), C.byref(rays))
+        self.lib.orc_render_texels_uv(self.h, C.byref(cfg), n, _p(pos), _p(nrm), None if uv is None else _p(uv),
+                                      _p(mid, c_int_p), _p(rgba, c_u8_p), _p(rgbf), C.byref(rays))
         return rgba, rgbf, rays.value
 
     def shade_records(self, records, material_id):

@@ -64,7 +64,11 @@ inline V3 bary(float u, float v, V3 a, V3 b, V3 c)
 struct Material {
 	V3 diffuse, specular;
 	float shininess, reflectivity, alpha, ior;
+	int texture;  // index into orc_scene::textures, -1 = NULL (data/data.h:25)
 };
+// data/data.h:7-16: RGBA8, rows in FreeImage_GetBits order (row 0 = the bottom scanline), which is
+// also the order glTexImage2D receives (ras_rasterizer.cpp:132): texel (x, y) = px[4 * (y*w + x)].
+struct Texture { int w, h; std::vector<uint8_t> px; };
 struct Light { V3 position, color; float energy; };
 struct Mesh {
 	std::vector<V3> verts, normals;
@@ -140,6 +144,34 @@ void inverse_transpose(const float* m, float* out)
 
 const float EPS_F = std::numeric_limits<float>::epsilon();  // rt_raytracer.cpp:18
 
+// Texture::lookup, data/data.cpp:35-57 [unpinned: FreeImage absent].  Returns 0..255 per channel.
+// FreeImage_GetPixelColor fails for x == width / y == height (u or v exactly 1.0) and the reference
+// then returns an uninitialised RGBQUAD; the restatement clamps to the last texel instead.
+V3 texture_lookup(const Texture& t, float u, float v)
+{
+	if (fabs(u) > 1) u = fmodf(u, 1.0f);
+	if (fabs(v) > 1) v = fmodf(v, 1.0f);
+	if (u < 0.0) u = (float)(u + 1.0);
+	if (v < 0.0) v = (float)(v + 1.0);
+	int x = (int)(u * (float)(unsigned)t.w);
+	int y = (int)(v * (float)(unsigned)t.h);
+	x = std::min(std::max(x, 0), t.w - 1);
+	y = std::min(std::max(y, 0), t.h - 1);
+	const uint8_t* c = &t.px[4 * ((size_t)y * t.w + x)];
+	return mk(c[0], c[1], c[2]);
+}
+
+// texture2D on a GL_NEAREST texture with the default GL_REPEAT wrap (ras_rasterizer.cpp:130-135,
+// mesh_fs.cpp:29) [unpinned: GL]: i = floor(frac(s) * w) clamped to w-1, UNORM8 -> c / 255.
+V3 texture_gl_nearest(const Texture& t, float u, float v)
+{
+	float fu = u - floorf(u), fv = v - floorf(v);
+	int x = std::min(std::max((int)floorf(fu * (float)t.w), 0), t.w - 1);
+	int y = std::min(std::max((int)floorf(fv * (float)t.h), 0), t.h - 1);
+	const uint8_t* c = &t.px[4 * ((size_t)y * t.w + x)];
+	return mk(c[0] / 255.0f, c[1] / 255.0f, c[2] / 255.0f);
+}
+
 // "x < 0.00001" with the literal a double (rt_accel_array.cpp:10,94,114): exact in double.
 inline bool lt_eps_array(float x) { return (double)x < 0.00001; }
 
@@ -147,6 +179,7 @@ inline bool lt_eps_array(float x) { return (double)x < 0.00001; }
 
 struct orc_scene {
 	std::vector<Material> materials;
+	std::vector<Texture> textures;
 	std::vector<Mesh> meshes;
 	std::vector<Light> lights;
 	std::vector<Tri> tris;        // world-space soup (processRays)
@@ -480,6 +513,7 @@ Material material_of(orc_scene* s, const HitMat& hm)
 		Material m;
 		memset(&m, 0, sizeof(m));
 		m.diffuse = s->spheres[hm.sphere].diffuse;
+		m.texture = -1;
 		return m;
 	}
 	return s->materials[hm.tri_material];
@@ -608,6 +642,8 @@ void shade(ShadeCtx& c, const orc_ray* ray, Material material, bool has_hm, HitM
 	float ref = material.reflectivity;
 	float alpha = material.alpha;
 	V3 diff_color = material.diffuse;
+	if (material.texture >= 0)  // rt_raytracer.cpp:93-95
+		diff_color = texture_lookup(s->textures[material.texture], ray->texcoord[0], ray->texcoord[1]);
 	const bool last = (pass + 1 >= c.cfg->bounces);  // children would return without writing
 
 	if (!c.cfg->use_photon_map) {
@@ -723,8 +759,23 @@ int orc_add_material(orc_scene* s, const float* d, const float* sp, float shinin
 	Material m;
 	m.diffuse = ld3(d); m.specular = ld3(sp);
 	m.shininess = shininess; m.reflectivity = reflectivity; m.alpha = alpha; m.ior = ior;
+	m.texture = -1;
 	s->materials.push_back(m);
 	return (int)s->materials.size() - 1;
+}
+
+// Material::texture = new Texture(path) (data/loader.cpp:110-121) with the decoded image handed in:
+// RGBA8, row 0 = bottom scanline.  rgba == NULL or width/height <= 0 removes the texture.
+int orc_set_texture(orc_scene* s, int material_id, const uint8_t* rgba, int width, int height)
+{
+	if (material_id < 0 || material_id >= (int)s->materials.size()) return -1;
+	if (!rgba || width <= 0 || height <= 0) { s->materials[material_id].texture = -1; return 0; }
+	Texture t;
+	t.w = width; t.h = height;
+	t.px.assign(rgba, rgba + (size_t)4 * width * height);
+	s->textures.push_back(t);
+	s->materials[material_id].texture = (int)s->textures.size() - 1;
+	return 0;
 }
 
 int orc_add_mesh(orc_scene* s, const float* verts, const float* normals, const float* texcoords,
@@ -996,6 +1047,14 @@ void orc_render_texels(orc_scene* s, const orc_shade_config* cfg, int n, const f
                        const float* nrm, const int* material_id, uint8_t* rgba, float* rgb_float,
                        int64_t* rays_issued)
 {
+	orc_render_texels_uv(s, cfg, n, pos, nrm, NULL, material_id, rgba, rgb_float, rays_issued);
+}
+
+// The same with the texels' texture coordinates (n x 2, NULL = (0,0): the record's zeroed default).
+void orc_render_texels_uv(orc_scene* s, const orc_shade_config* cfg, int n, const float* pos,
+                          const float* nrm, const float* uv, const int* material_id, uint8_t* rgba,
+                          float* rgb_float, int64_t* rays_issued)
+{
 	if (cfg->geometry == 0) ensure_array(s); else ensure_spheres(s);
 	ShadeCtx c = {s, cfg, 0};
 	for (int i = 0; i < n; ++i) {
@@ -1010,6 +1069,7 @@ void orc_render_texels(orc_scene* s, const orc_shade_config* cfg, int n, const f
 		st3(r.position, P);
 		st3(r.normal, ld3(nrm + 3 * i));
 		st3(r.direction, normalized(P));  // eye at the origin (prepass_vs.cpp:12-13)
+		if (uv) { r.texcoord[0] = uv[2 * i]; r.texcoord[1] = uv[2 * i + 1]; }
 		V3 col = mk(0, 0, 0);
 		// ids past the user table address the per-sphere materials (sphere geometry only)
 		HitMat hm = {material_id[i], -1};
@@ -1034,6 +1094,8 @@ void orc_shade_records(orc_scene* s, int n, const orc_ray* records, const int* m
 	for (int i = 0; i < n; ++i) {
 		const Material& m = s->materials[material_id[i]];
 		V3 albedo = divs(m.diffuse, 255.0f), scol = divs(m.specular, 255.0f);
+		if (m.texture >= 0)  // material_textured == 1 (mesh_fs.cpp:29-30)
+			albedo = texture_gl_nearest(s->textures[m.texture], records[i].texcoord[0], records[i].texcoord[1]);
 		V3 pos = ld3(records[i].position);
 		V3 N = normalized(ld3(records[i].normal));
 		V3 E = normalized(neg(pos));

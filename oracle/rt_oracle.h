@@ -35,6 +35,8 @@ orc_scene* orc_scene_create(void);
 void orc_scene_destroy(orc_scene* s);
 int orc_add_material(orc_scene* s, const float* diffuse3, const float* specular3, float shininess,
                      float reflectivity, float alpha, float ior);
+/* Material::texture (data/data.h:25): decoded RGBA8 image, row 0 = bottom scanline; NULL removes. */
+int orc_set_texture(orc_scene* s, int material_id, const uint8_t* rgba, int width, int height);
 int orc_add_mesh(orc_scene* s, const float* verts, const float* normals, const float* texcoords,
                  int nverts, const uint32_t* faces, int nfaces, const float* model_mat16,
                  int material_id, const float* position3);
@@ -88,6 +90,12 @@ int orc_gbuffer_select(int n, const float* nrm_rgba, const float* pos_rgb, int i
 void orc_render_texels(orc_scene* s, const orc_shade_config* cfg, int n, const float* pos,
                        const float* nrm, const int* material_id, uint8_t* rgba, float* rgb_float,
                        int64_t* rays_issued);
+
+/* The same with per-texel texture coordinates (n x 2 floats, NULL = zeros): Texture::lookup
+ * (data/data.cpp:35-57) replaces the diffuse colour of textured materials (rt_raytracer.cpp:93-95). */
+void orc_render_texels_uv(orc_scene* s, const orc_shade_config* cfg, int n, const float* pos,
+                          const float* nrm, const float* uv, const int* material_id, uint8_t* rgba,
+                          float* rgb_float, int64_t* rays_issued);
 
 /* a20: live shading equation (mesh_fs.cpp:26-49) for hit records; rgb out n x 3 floats (0..1). */
 void orc_shade_records(orc_scene* s, int n, const orc_ray* records, const int* material_id,

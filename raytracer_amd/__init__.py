@@ -64,7 +64,8 @@ ABI_SYMBOLS = [
     "rt_hip_photon_set_device", "rt_hip_photon_set", "rt_hip_radiance_estimate_device", "rt_hip_radiance_estimate",
     "rt_hip_shade_results", "rt_hip_shade_results_device", "rt_hip_pack_tiles_device", "rt_hip_unpack_tiles_device",
     "rt_hip_render_tiles_batch_device", "rt_hip_live_frame_device", "rt_hip_render_tiles_packed_device",
-    "rt_hip_unpack_chunks_device",
+    "rt_hip_unpack_chunks_device", "rt_hip_set_texture", "rt_hip_set_frame_texcoords_device",
+    "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device",
 ]
@@ -125,6 +126,9 @@ def load_library() -> C.CDLL:
     L.rt_hip_trace_census_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
     L.rt_hip_gbuffer_select_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, c_int_p]
     L.rt_hip_render_gbuffer_device.argtypes = [P, C.c_float, C.c_int, C.c_int, P, P]
+    L.rt_hip_render_gbuffer_uv_device.argtypes = [P, C.c_float, C.c_int, C.c_int, P, P, P]
+    L.rt_hip_set_texture.argtypes = [P, C.c_int, P, C.c_int, C.c_int]
+    L.rt_hip_set_frame_texcoords_device.argtypes = [P, P, C.c_int]
     L.rt_hip_render_frame.argtypes = [P, c_float_p, c_float_p, C.c_int, C.c_int, c_u8_p]
     L.rt_hip_render_frame_device.argtypes = [P, P, P, C.c_int, C.c_int, P]
     L.rt_hip_render_tiles_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
@@ -245,6 +249,9 @@ class RtHip:
         for i, m in enumerate(scene.materials):
             mats[i] = (m.diffuse, m.specular, m.shininess, m.reflectivity, m.alpha, m.ior, 0)
         self._ck(self.lib.rt_hip_set_materials(self.h, mats.ctypes.data_as(C.c_void_p), len(mats)))
+        for i, m in enumerate(scene.materials):
+            if getattr(m, "texture", None) is not None:
+                self.set_texture(i, m.texture)
         lights = np.zeros(len(scene.lights), LIGHT_DTYPE)
         for i, li in enumerate(scene.lights):
             lights[i] = (li.position, li.color, li.energy)
@@ -258,6 +265,17 @@ class RtHip:
 
     def update(self):
         self._ck(self.lib.rt_hip_update(self.h))
+
+    def set_texture(self, material_id, rgba):
+        """Material::texture: (h, w, 4) u8 RGBA with row 0 = the bottom scanline, or None to remove.  Takes effect
+        at the next update()."""
+        if rgba is None:
+            self._ck(self.lib.rt_hip_set_texture(self.h, material_id, None, 0, 0))
+            return
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        if rgba.ndim != 3 or rgba.shape[2] != 4:
+            raise ValueError("texture must be (h, w, 4) u8")
+        self._ck(self.lib.rt_hip_set_texture(self.h, material_id, rgba.ctypes.data_as(C.c_void_p), rgba.shape[1], rgba.shape[0]))
 
     def set_model_mat(self, mesh_id, model_colmajor16):
         """Mesh::model_mat of one mesh (column-major 4x4); takes effect at the next update()."""
@@ -343,6 +361,17 @@ class RtHip:
 
     def render_gbuffer_device(self, fov, w, h, d_nrm_rgba, d_pos_rgb):
         self._ck(self.lib.rt_hip_render_gbuffer_device(self.h, fov, w, h, _dptr(d_nrm_rgba), _dptr(d_pos_rgb)))
+
+    def render_gbuffer_uv_device(self, fov, w, h, d_nrm_rgba, d_pos_rgb, d_uv):
+        self._ck(self.lib.rt_hip_render_gbuffer_uv_device(self.h, fov, w, h, _dptr(d_nrm_rgba), _dptr(d_pos_rgb), _dptr(d_uv)))
+
+    def set_frame_texcoords_device(self, d_uv_list):
+        """Level-0 texture coordinates (w*h x 2 f32 per frame) for the frame calls that follow; [] clears.  The
+        tensors must stay alive until replaced."""
+        n = len(d_uv_list)
+        arr = (C.c_void_p * max(n, 1))(*[_dptr(t) for t in d_uv_list])
+        self._frame_uv_keepalive = list(d_uv_list)
+        self._ck(self.lib.rt_hip_set_frame_texcoords_device(self.h, arr if n else None, n))
 
     def render_frame_device(self, d_pos_rgb, d_nrm_rgba, w, h, d_rgba):
         self._ck(self.lib.rt_hip_render_frame_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, _dptr(d_rgba)))

@@ -105,6 +105,45 @@ __device__ __forceinline__ void resolve_tri(const SceneView& sv, const Hit& h, H
 	}
 }
 
+// ---- textures ---------------------------------------------------------------------
+// Texture::lookup (data/data.cpp:35-57): 0..255 per channel.  FreeImage_GetPixelColor fails for
+// x == width / y == height (u or v exactly 1) and the reference then returns an uninitialised colour;
+// defined here (and in the oracle) as the last texel.
+__device__ __forceinline__ f3 tex_lookup_ref(const TexRec t, const uint32_t* __restrict__ texels, float u, float v)
+{
+	if (fabsf(u) > 1.0f) u = fmodf(u, 1.0f);
+	if (fabsf(v) > 1.0f) v = fmodf(v, 1.0f);
+	if (u < 0.0f) u = (float)((double)u + 1.0);
+	if (v < 0.0f) v = (float)((double)v + 1.0);
+	int x = (int)(u * (float)(unsigned)t.w);
+	int y = (int)(v * (float)(unsigned)t.h);
+	x = min(max(x, 0), t.w - 1);
+	y = min(max(y, 0), t.h - 1);
+	const uint32_t c = texels[t.offset + (size_t)y * t.w + x];
+	return mk3((float)(c & 255u), (float)((c >> 8) & 255u), (float)((c >> 16) & 255u));
+}
+
+// texture2D on the GL_NEAREST texture with the default GL_REPEAT wrap (ras_rasterizer.cpp:130-135,
+// mesh_fs.cpp:29): i = floor(frac(s) * w), UNORM8 -> c / 255.
+__device__ __forceinline__ f3 tex_lookup_gl(const TexRec t, const uint32_t* __restrict__ texels, float u, float v)
+{
+	const float fu = u - floorf(u), fv = v - floorf(v);
+	const int x = min(max((int)floorf(fu * (float)t.w), 0), t.w - 1);
+	const int y = min(max((int)floorf(fv * (float)t.h), 0), t.h - 1);
+	const uint32_t c = texels[t.offset + (size_t)y * t.w + x];
+	return mk3((float)(c & 255u) / 255.0f, (float)((c >> 8) & 255u) / 255.0f, (float)((c >> 16) & 255u) / 255.0f);
+}
+
+// mesh_fs.cpp:29-30: albedo = material_textured ? texture2D(...).rgb : material_color (= diffuse / 255)
+__device__ __forceinline__ f3 live_albedo(const SceneView& sv, int mat, const MaterialRec& m, float u, float v)
+{
+	if (sv.tex) {
+		const TexRec t = sv.tex[mat];
+		if (t.w > 0) return tex_lookup_gl(t, sv.texels, u, v);
+	}
+	return div3(ld3(m.diffuse), 255.0f);
+}
+
 // Count convention of the frame kernels: `n` is the item count, or -- when n_ptr != nullptr -- the
 // capacity, and the count is min(n, *n_ptr) read on the device (the sync-free frame path never
 // brings a count back to the host between launches).
@@ -273,7 +312,7 @@ __host__ __device__ inline int tile8_count(int w, int h) { return ((w + 7) >> 3)
 
 __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, float tanfov, int w, int h,
                                                                  float* __restrict__ nrm_rgba,
-                                                                 float* __restrict__ pos_rgb)
+                                                                 float* __restrict__ pos_rgb, float* __restrict__ uv)
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
@@ -289,6 +328,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
 		f3 D = mk3(dirX * tanfov, dirY * tanfov, -1.0f);
 		f3 O = mk3(0, 0, 0);
 		float alpha = 0.0f;
+		float tc[2] = {0.0f, 0.0f};
 		f3 P = mk3(0, 0, 0), N = mk3(0, 0, 1);
 		if (sv.num_spheres > 0 && sv.num_tris == 0) {
 			// nearest sphere along the TRUE ray (the G-buffer producer stands in for the rasterizer,
@@ -307,7 +347,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
 			scene_trace<false>(sv, O, D, best, stack, TRACE_BLOCK, spill);
 			if (best.prim != RT_MISS) {
 				HitInfo hi;
-				resolve_tri(sv, best, hi, nullptr);
+				resolve_tri(sv, best, hi, uv ? tc : nullptr);
 				P = ld3(hi.pos); N = ld3(hi.nrm);
 				alpha = (float)(hi.material + 1);
 			}
@@ -320,6 +360,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
 		pos_rgb[3 * (size_t)i + 0] = half_round(P.x);
 		pos_rgb[3 * (size_t)i + 1] = half_round(P.y);
 		pos_rgb[3 * (size_t)i + 2] = half_round(P.z);
+		if (uv) { uv[2 * (size_t)i] = tc[0]; uv[2 * (size_t)i + 1] = tc[1]; }
 	});
 }
 
@@ -340,7 +381,8 @@ __device__ __forceinline__ bool tile_is_mine(int pixel, int w, int tile, int ran
 __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__ pos_rgb,
                                                       const float* __restrict__ nrm_rgba, int w, int h, int n0, int tile,
                                                       int rank, int nranks, int num_materials,
-                                                      NodeGeo* __restrict__ geo, int* __restrict__ active_count)
+                                                      NodeGeo* __restrict__ geo, int* __restrict__ active_count,
+                                                      const float* __restrict__ uv_plane, float* __restrict__ node_uv)
 {
 	int j = blockIdx.x * CBLOCK + threadIdx.x;
 	bool active = false;
@@ -365,6 +407,11 @@ __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__
 		g.parent = i; g.material = mat; g.branch = 0;
 		geo[j] = g;
 		active = mat >= 0;
+		if (node_uv) {  // textured scenes only
+			const bool have = uv_plane && i >= 0;
+			node_uv[2 * (size_t)j] = have ? uv_plane[2 * (size_t)i] : 0.0f;
+			node_uv[2 * (size_t)j + 1] = have ? uv_plane[2 * (size_t)i + 1] : 0.0f;
+		}
 	}
 	// one counter add per workgroup
 	__shared__ int s_cnt;
@@ -402,7 +449,8 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
                                                       NodeShade* __restrict__ shade, int* __restrict__ gate,
                                                       unsigned int* __restrict__ occl, float* __restrict__ q_org,
                                                       float* __restrict__ q_dir, int* __restrict__ q_parent,
-                                                      int* __restrict__ q_count, int* __restrict__ active_count)
+                                                      int* __restrict__ q_count, int* __restrict__ active_count,
+                                                      float* __restrict__ node_uv)
 {
 	int j = blockIdx.x * CBLOCK + threadIdx.x;
 	bool active = false, emit = false;
@@ -440,6 +488,12 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
 		shade[j] = s;
 		gate[j] = active ? mat : -1;
 		if (occl) occl[j] = 0u;
+		if (node_uv) {  // textured scenes only
+			const float* __restrict__ uvp = fs.uv[f];
+			const bool have = uvp && i >= 0;
+			node_uv[2 * (size_t)j] = have ? uvp[2 * (size_t)i] : 0.0f;
+			node_uv[2 * (size_t)j + 1] = have ? uvp[2 * (size_t)i + 1] : 0.0f;
+		}
 		if (active && recurse && sv.materials[mat].reflectivity > 0.0f) {
 			R = I - N * (2.0f * dot3(I, N));
 			emit = true;
@@ -664,15 +718,21 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
                                                          int* __restrict__ gate, NodeGeo* __restrict__ child_geo,
                                                          unsigned int* __restrict__ child_occl,
                                                          int* __restrict__ child_count, int child_capacity,
-                                                         int* __restrict__ overflow)
+                                                         int* __restrict__ overflow, const Hit* __restrict__ tc_hits,
+                                                         float* __restrict__ child_uv)
 {
 	nq = dev_count(nq, n_ptr);
 	int i = blockIdx.x * CBLOCK + threadIdx.x;
 	bool hit = false;
 	HitInfo h;
+	float tc[2] = {0.0f, 0.0f};
 	if (i < nq) {
-		if (raw_hits) resolve_tri(sv, raw_hits[i], h, nullptr);
-		else h = hi[i];
+		if (raw_hits) resolve_tri(sv, raw_hits[i], h, child_uv ? tc : nullptr);
+		else {
+			h = hi[i];
+			// textured scenes: IAccel::intersect's texcoord write-back from the queue's raw hits (spheres: none)
+			if (child_uv && tc_hits && h.material >= 0) { HitInfo tmp; resolve_tri(sv, tc_hits[i], tmp, tc); }
+		}
 		hit = h.material >= 0;
 		if (hit && branch == 0) gate[q_parent[i]] = h.material;  // Q9: reflection hit overwrites `material`
 	}
@@ -686,6 +746,7 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
 		g.branch = branch;
 		child_geo[slot] = g;
 		if (child_occl) child_occl[slot] = 0u;
+		if (child_uv) { child_uv[2 * (size_t)slot] = tc[0]; child_uv[2 * (size_t)slot + 1] = tc[1]; }
 	}
 }
 
@@ -696,7 +757,8 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
                                                    const int* __restrict__ n_ptr, int level,
                                                    NodeShade* __restrict__ parent_shade, FrameSet fs, int frame_pixels,
                                                    float* __restrict__ rgb_float, int lit,
-                                                   const unsigned int* __restrict__ occl)
+                                                   const unsigned int* __restrict__ occl,
+                                                   const float* __restrict__ node_uv)
 {
 	n = dev_count(n, n_ptr);
 	int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -709,7 +771,12 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 		const NodeShade s = shade[i];
 		float ref = m.reflectivity, alpha = m.alpha;
 		float kd = (float)(1.0 - (double)ref - (double)alpha);
-		f3 mix = (ld3(m.diffuse) * kd + ld3(s.refc) * ref) + ld3(s.refrc) * alpha;
+		f3 diff = ld3(m.diffuse);
+		if (node_uv) {  // textured scenes only: diff_color = texture->lookup(texcoord) (rt_raytracer.cpp:93-95)
+			const TexRec t = sv.tex[g.material];
+			if (t.w > 0) diff = tex_lookup_ref(t, sv.texels, node_uv[2 * (size_t)i], node_uv[2 * (size_t)i + 1]);
+		}
+		f3 mix = (diff * kd + ld3(s.refc) * ref) + ld3(s.refrc) * alpha;
 		f3 F = ld3(s.F);
 		if (lit) {  // deferred light_color(): the level's shadow rays have landed by now
 			float f = light_factor(sv, ld3(g.V), ld3(g.N), occl ? occl[i] : 0u);
@@ -747,10 +814,10 @@ __global__ __launch_bounds__(BLOCK) void k_node_points(const NodeGeo* __restrict
 // mesh_fs.cpp:26-49: per light energy = color/255 * 50/(50+|L|^2); direct += energy*albedo*clamp(N.L)
 // + energy*scolor*pow(clamp(N.H), shininess), E = normalize(-pos); color = refl*reflection +
 // (1-refl)*direct.  Material and light colours / 255 (ras_rasterizer.cpp:184-188,232); at most
-// LIGHT_COUNT = 8 lights (mesh_fs.cpp:5); untextured (Texture::lookup is SURVEY 8f row 3).
-__device__ __forceinline__ f3 mesh_fs_color(const SceneView& sv, const MaterialRec& m, f3 pos, f3 nrm, f3 reflection)
+// LIGHT_COUNT = 8 lights (mesh_fs.cpp:5); albedo from live_albedo() (texture or material colour).
+__device__ __forceinline__ f3 mesh_fs_color(const SceneView& sv, const MaterialRec& m, f3 albedo, f3 pos, f3 nrm, f3 reflection)
 {
-	f3 albedo = div3(ld3(m.diffuse), 255.0f), scol = div3(ld3(m.specular), 255.0f);
+	f3 scol = div3(ld3(m.specular), 255.0f);
 	f3 N = normalized3(nrm);
 	f3 E = normalized3(neg3(pos));
 	f3 direct = mk3(0, 0, 0);
@@ -785,9 +852,11 @@ __global__ __launch_bounds__(BLOCK) void k_live_raypass(SceneView sv, const Hit*
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
 	HitInfo hi;
-	resolve_tri(sv, hits[i], hi, nullptr);
+	float tc[2] = {0.0f, 0.0f};
+	resolve_tri(sv, hits[i], hi, sv.tex ? tc : nullptr);
 	if (hi.material < 0) return;
-	f3 c = mesh_fs_color(sv, sv.materials[hi.material], ld3(hi.pos), ld3(hi.nrm), mk3(0, 0, 0));
+	const MaterialRec m = sv.materials[hi.material];
+	f3 c = mesh_fs_color(sv, m, live_albedo(sv, hi.material, m, tc[0], tc[1]), ld3(hi.pos), ld3(hi.nrm), mk3(0, 0, 0));
 	uint8_t* px = raypass + 3 * (size_t)texel[i];
 	px[0] = unorm8(c.x); px[1] = unorm8(c.y); px[2] = unorm8(c.z);
 }
@@ -797,7 +866,8 @@ __global__ __launch_bounds__(BLOCK) void k_live_raypass(SceneView sv, const Hit*
 // GL_LINEAR fetch returns the texel), background = the clear colour 0.3.
 __global__ __launch_bounds__(BLOCK) void k_live_composite(SceneView sv, const float* __restrict__ pos_rgb,
                                                           const float* __restrict__ nrm_rgba, int n,
-                                                          const uint8_t* __restrict__ raypass, uint8_t* __restrict__ rgba)
+                                                          const uint8_t* __restrict__ raypass, uint8_t* __restrict__ rgba,
+                                                          const float* __restrict__ uv)
 {
 	int i = blockIdx.x * BLOCK + threadIdx.x;
 	if (i >= n) return;
@@ -812,7 +882,9 @@ __global__ __launch_bounds__(BLOCK) void k_live_composite(SceneView sv, const fl
 	N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
 	const uint8_t* rp = raypass + 3 * (size_t)i;
 	f3 refl = mk3(rp[0] / 255.0f, rp[1] / 255.0f, rp[2] / 255.0f);
-	f3 c = mesh_fs_color(sv, sv.materials[mat], ld3(pos_rgb + 3 * (size_t)i), N, refl);
+	const MaterialRec m = sv.materials[mat];
+	const float tu = uv ? uv[2 * (size_t)i] : 0.0f, tv = uv ? uv[2 * (size_t)i + 1] : 0.0f;
+	f3 c = mesh_fs_color(sv, m, live_albedo(sv, mat, m, tu, tv), ld3(pos_rgb + 3 * (size_t)i), N, refl);
 	px[0] = unorm8(c.x); px[1] = unorm8(c.y); px[2] = unorm8(c.z); px[3] = 255;
 }
 
@@ -831,8 +903,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade_results(SceneView sv, const rt_
 		int mid = (lo + hi) >> 1;
 		if (groups[mid].end > i) hi = mid; else lo = mid + 1;
 	}
-	const MaterialRec m = sv.materials[groups[lo].material];
-	f3 c = mesh_fs_color(sv, m, ld3(rec[i].position), ld3(rec[i].normal), mk3(0, 0, 0));
+	const int mat = groups[lo].material;
+	const MaterialRec m = sv.materials[mat];
+	const float* tcp = (const float*)(rec + i) + 12;  // Ray::texcoord
+	f3 c = mesh_fs_color(sv, m, live_albedo(sv, mat, m, tcp[0], tcp[1]), ld3(rec[i].position), ld3(rec[i].normal), mk3(0, 0, 0));
 	st3(rgb + 3 * (size_t)i, c);
 	if (rgb8) {  // GL UNORM8 conversion of the RGB8 raypass target
 		rgb8[3 * (size_t)i + 0] = unorm8(c.x);
@@ -958,7 +1032,7 @@ int rt_live_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rg
 		                   ctx->d_ray_parent.as<int>(), count, d_raypass);
 	}
 	hipLaunchKernelGGL(k_live_composite, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, d_pos_rgb, d_nrm_rgba, n,
-	                   d_raypass, d_rgba);
+	                   d_raypass, d_rgba, ctx->frame_uv_count > 0 ? ctx->frame_uv[0] : (const float*)nullptr);
 	RT_HIP_CHECK(hipGetLastError());
 	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	RT_CHECK(rt_collect_timing(ctx));
@@ -1120,13 +1194,13 @@ int rt_gbuffer_select(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_p
 	return RT_HIP_OK;
 }
 
-int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb)
+int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb, float* d_uv)
 {
 	SceneView sv = rt_scene_view(ctx);
 	float tanfov = tanf(fov);  // Camera::setFOV (data/camera.cpp:41-44)
 	size_t lds = rt_trace_lds(sv, TRACE_BLOCK);
 	hipLaunchKernelGGL(k_primary_gbuffer, dim3(rt_trace_blocks(ctx, tile8_count(w, h), TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, ctx->stream,
-	                   sv, tanfov, w, h, d_nrm_rgba, d_pos_rgb);
+	                   sv, tanfov, w, h, d_nrm_rgba, d_pos_rgb, d_uv);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }
@@ -1212,6 +1286,9 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	RT_CHECK(ctx->d_nodes_a.reserve((size_t)off[bounces] * sizeof(NodeGeo)));
 	RT_CHECK(ctx->d_nodes_b.reserve((size_t)off[bounces] * sizeof(NodeShade)));
 	RT_CHECK(ctx->d_gate.reserve((size_t)off[bounces] * sizeof(int)));
+	if (sv.tex) RT_CHECK(ctx->d_node_uv.reserve((size_t)off[bounces] * 8));  // textured scenes: a texcoord per node
+	float* const uv_base = sv.tex ? ctx->d_node_uv.as<float>() : nullptr;
+	auto level_uv = [&](int L) -> float* { return uv_base ? uv_base + 2 * (size_t)off[L] : nullptr; };
 	RT_CHECK(ctx->d_rays_q.reserve((size_t)maxcap * 24));
 	RT_CHECK(ctx->d_ray_parent.reserve((size_t)maxcap * 4));
 	RT_CHECK(ctx->d_records.reserve((size_t)maxcap * sizeof(HitInfo)));
@@ -1269,7 +1346,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		if (L == 0) {
 			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
 			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, fs, w, h, n0,
-			                   tile, rank, nranks, recurse ? 1 : 0, geo, shade, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0);
+			                   tile, rank, nranks, recurse ? 1 : 0, geo, shade, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
 		} else {
 			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created
 			hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, n_ptr,
@@ -1294,8 +1371,10 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr));
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 1));
 		}
+		// texcoords of the children: from the queue's raw hits (trace_queue leaves them in d_hits for triangles)
+		const Hit* tc_hits = (sv.num_spheres > 0 && sv.num_tris == 0) ? nullptr : ctx->d_hits.as<Hit>();
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
-		                   lc + 1, 0, gate, child_geo, child_occl, child_count, child_cap, fc + 1);
+		                   lc + 1, 0, gate, child_geo, child_occl, child_count, child_cap, fc + 1, tc_hits, level_uv(L + 1));
 		// refraction, gated after the reflection hits are known (Q9)
 		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, n_ptr, gate, q_org, q_dir,
 		                   q_parent, lc + 2);
@@ -1303,7 +1382,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		if (fuse) RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2));
 		else RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
-		                   lc + 2, 1, gate, child_geo, child_occl, child_count, child_cap, fc + 1);
+		                   lc + 2, 1, gate, child_geo, child_occl, child_count, child_cap, fc + 1, tc_hits, level_uv(L + 1));
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	for (int L = bounces - 1; L >= 0; --L) {
@@ -1313,7 +1392,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + off[L - 1] : nullptr;
 		const unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
 		hipLaunchKernelGGL(k_combine, dim3(nblocks((int)cap[L], BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, (int)cap[L], n_ptr, L,
-		                   pshade, fs, fs.packed ? fs.per_frame : w * h, (float*)nullptr, 1, occl);
+		                   pshade, fs, fs.packed ? fs.per_frame : w * h, (float*)nullptr, 1, occl, level_uv(L));
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	int* h_fc = (int*)ctx->h_small;  // 4 KiB pinned; nfc <= 80 ints
@@ -1346,8 +1425,8 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	return RT_HIP_OK;
 }
 
-static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
-                             int rank, int nranks, uint8_t* d_rgba);
+static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, const float* d_uv, int w, int h,
+                             int tile, int rank, int nranks, uint8_t* d_rgba);
 
 int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
                      int h, int tile, int rank, int nranks, uint8_t* const* d_rgba, int packed)
@@ -1367,7 +1446,10 @@ int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float
 		memset(&fs, 0, sizeof(fs));
 		fs.nframes = nframes;
 		fs.packed = packed;
-		for (int f = 0; f < nframes; ++f) { fs.pos[f] = d_pos_rgb[f]; fs.nrm[f] = d_nrm_rgba[f]; fs.rgba[f] = d_rgba[f]; }
+		for (int f = 0; f < nframes; ++f) {
+			fs.pos[f] = d_pos_rgb[f]; fs.nrm[f] = d_nrm_rgba[f]; fs.rgba[f] = d_rgba[f];
+			fs.uv[f] = f < ctx->frame_uv_count ? ctx->frame_uv[f] : nullptr;
+		}
 		bool overflowed = false, declined = false;
 		RT_CHECK(render_frame_async(ctx, fs, w, h, tile, rank, nranks, &overflowed, &declined));
 		if (!overflowed && !declined) return RT_HIP_OK;
@@ -1386,7 +1468,8 @@ int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float
 			RT_CHECK(ctx->d_offsets.reserve((size_t)w * h * 4));
 			target = ctx->d_offsets.as<uint8_t>();
 		}
-		RT_CHECK(render_frame_sync(ctx, d_pos_rgb[f], d_nrm_rgba[f], w, h, tile, rank, nranks, target));
+		RT_CHECK(render_frame_sync(ctx, d_pos_rgb[f], d_nrm_rgba[f], f < ctx->frame_uv_count ? ctx->frame_uv[f] : nullptr, w, h, tile,
+		                           rank, nranks, target));
 		rays += ctx->last_frame_rays;
 		if (packed) {
 			const int* list; int nt;
@@ -1405,8 +1488,8 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
 	return rt_render_frames(ctx, &d_pos_rgb, &d_nrm_rgba, 1, w, h, tile, rank, nranks, &d_rgba);
 }
 
-static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
-                             int rank, int nranks, uint8_t* d_rgba)
+static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, const float* d_uv, int w, int h,
+                             int tile, int rank, int nranks, uint8_t* d_rgba)
 {
 	hipStream_t st = ctx->stream;
 	SceneView sv = rt_scene_view(ctx);
@@ -1428,8 +1511,11 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		RT_CHECK(ctx->d_nodes_a.reserve(nodes * sizeof(NodeGeo)));
 		RT_CHECK(ctx->d_nodes_b.reserve(nodes * sizeof(NodeShade)));
 		RT_CHECK(ctx->d_gate.reserve(nodes * sizeof(int)));
+		if (sv.tex) RT_CHECK(ctx->d_node_uv.reserve(nodes * 8));  // textured scenes: a texcoord per node
 		return RT_HIP_OK;
 	};
+	// (re)fetched at every use: reserve() may move the buffer
+	auto level_uv = [&](size_t node_off) -> float* { return sv.tex ? ctx->d_node_uv.as<float>() + 2 * node_off : nullptr; };
 	// worst case for the next level is 2 children per node; reserve level 0 + level 1 bound up front
 	RT_CHECK(ensure_nodes((size_t)npix * (bounces > 1 ? 3 : 1)));
 	RT_CHECK(ctx->d_qcount.reserve(64));
@@ -1439,7 +1525,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
 	RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 64, st));
 	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(npix, CBLOCK)), dim3(CBLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, npix, tile, rank,
-	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), qcount + 8);
+	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), qcount + 8, d_uv, level_uv(0));
 	RT_HIP_CHECK(hipGetLastError());
 	int active0 = 0;
 	RT_HIP_CHECK(hipMemcpyAsync(&active0, qcount + 8, 4, hipMemcpyDeviceToHost, st));
@@ -1517,12 +1603,14 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		geo = ctx->d_nodes_a.as<NodeGeo>() + geo_off[L];
 		gate = ctx->d_gate.as<int>() + geo_off[L];
 		NodeGeo* child_geo = ctx->d_nodes_a.as<NodeGeo>() + geo_off[L + 1];
+		const Hit* tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();  // trace_queue leaves the raw hits there
 		if (nq > 0) {
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
 			rays += nq;
+			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
 			                   q_parent, nq, (const int*)nullptr, 0, gate, child_geo, (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
-			                   qcount + 2);
+			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]));
 			RT_HIP_CHECK(hipGetLastError());
 		}
 		// refraction, gated after the reflection hits are known (Q9)
@@ -1536,9 +1624,10 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		if (nq > 0) {
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, nq, d_hi));
 			rays += nq;
+			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
 			                   q_parent, nq, (const int*)nullptr, 1, gate, child_geo, (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
-			                   qcount + 2);
+			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]));
 			RT_HIP_CHECK(hipGetLastError());
 			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
 			RT_HIP_CHECK(hipStreamSynchronize(st));
@@ -1556,7 +1645,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + geo_off[L];
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + geo_off[L - 1] : nullptr;
 		hipLaunchKernelGGL(k_combine, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, (const int*)nullptr, L,
-		                   pshade, fs1, w * h, (float*)nullptr, 0, (const unsigned int*)nullptr);
+		                   pshade, fs1, w * h, (float*)nullptr, 0, (const unsigned int*)nullptr, level_uv(geo_off[L]));
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));

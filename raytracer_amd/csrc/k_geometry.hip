@@ -156,6 +156,24 @@ int rt_build_geometry(rt_hip_ctx* ctx)
 		RT_CHECK(ctx->d_materials.reserve(std::max<size_t>(mr.size(), 1) * sizeof(MaterialRec)));
 		if (!mr.empty())
 			RT_HIP_CHECK(hipMemcpyAsync(ctx->d_materials.p, mr.data(), mr.size() * sizeof(MaterialRec), hipMemcpyHostToDevice, st));
+		// textures: one record per material, texels of all textures in one pool
+		ctx->any_texture = false;
+		for (size_t i = 0; i < ctx->textures.size() && i < nuser; ++i) ctx->any_texture |= ctx->textures[i].w > 0;
+		if (ctx->any_texture) {
+			std::vector<TexRec> tr(mr.size());
+			memset(tr.data(), 0, tr.size() * sizeof(TexRec));
+			std::vector<uint32_t> pool;
+			for (size_t i = 0; i < ctx->textures.size() && i < nuser; ++i) {
+				const HostTexture& t = ctx->textures[i];
+				if (t.w <= 0) continue;
+				tr[i].offset = (uint32_t)pool.size(); tr[i].w = t.w; tr[i].h = t.h;
+				pool.insert(pool.end(), t.texels.begin(), t.texels.end());
+			}
+			RT_CHECK(ctx->d_tex.reserve(tr.size() * sizeof(TexRec)));
+			RT_CHECK(ctx->d_texels.reserve(pool.size() * 4));
+			RT_HIP_CHECK(hipMemcpy(ctx->d_tex.p, tr.data(), tr.size() * sizeof(TexRec), hipMemcpyHostToDevice));
+			RT_HIP_CHECK(hipMemcpy(ctx->d_texels.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
+		}
 		std::vector<LightRec> lr(ctx->lights.size());
 		for (size_t i = 0; i < lr.size(); ++i) {
 			for (int k = 0; k < 3; ++k) { lr[i].position[k] = ctx->lights[i].position[k]; lr[i].color[k] = ctx->lights[i].color[k]; }

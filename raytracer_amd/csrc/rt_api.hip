@@ -123,6 +123,8 @@ SceneView rt_scene_view(const rt_hip_ctx* ctx)
 	sv.spheres = ctx->d_spheres.as<SphereRec>();
 	sv.materials = ctx->d_materials.as<MaterialRec>();
 	sv.lights = ctx->d_lights.as<LightRec>();
+	sv.tex = ctx->any_texture ? ctx->d_tex.as<TexRec>() : nullptr;
+	sv.texels = ctx->d_texels.as<uint32_t>();
 	sv.num_tris = ctx->cfg.geometry == RT_HIP_SPHERES ? 0 : ctx->num_tris;
 	sv.num_spheres = ctx->cfg.geometry == RT_HIP_SPHERES ? (int)ctx->spheres.size() : 0;
 	sv.num_materials = (int)ctx->materials.size() + sv.num_spheres;
@@ -304,7 +306,8 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_hits, &ctx->d_occ, &ctx->d_in_a, &ctx->d_in_b, &ctx->d_records, &ctx->d_offsets, &ctx->d_keys,
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
-	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list, &ctx->d_all_tiles};
+	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list, &ctx->d_all_tiles,
+	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);
@@ -345,7 +348,34 @@ int rt_hip_set_materials(rt_hip_ctx* ctx, const rt_material* materials, int n)
 	RT_CHECK(check_ctx(ctx));
 	if (n < 0 || (n > 0 && !materials)) { rt_set_error("bad material table"); return RT_HIP_ERR_ARG; }
 	ctx->materials.assign(materials, materials + n);
+	ctx->textures.clear();  // a texture belongs to its Material object (data/data.h:25): new table, no textures
 	ctx->scene_dirty = true;
+	return RT_HIP_OK;
+}
+
+int rt_hip_set_texture(rt_hip_ctx* ctx, int material_id, const uint8_t* rgba, int width, int height)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (material_id < 0 || material_id >= (int)ctx->materials.size()) { rt_set_error("material %d out of range", material_id); return RT_HIP_ERR_ARG; }
+	if (rgba && (width <= 0 || height <= 0 || (int64_t)width * height > (int64_t)1 << 28)) { rt_set_error("bad texture size %d x %d", width, height); return RT_HIP_ERR_ARG; }
+	if ((int)ctx->textures.size() <= material_id) ctx->textures.resize(material_id + 1);
+	HostTexture& t = ctx->textures[material_id];
+	t.w = t.h = 0; t.texels.clear();
+	if (rgba) {
+		t.w = width; t.h = height;
+		t.texels.resize((size_t)width * height);
+		memcpy(t.texels.data(), rgba, (size_t)width * height * 4);
+	}
+	ctx->scene_dirty = true;
+	return RT_HIP_OK;
+}
+
+int rt_hip_set_frame_texcoords_device(rt_hip_ctx* ctx, const float* const* d_uv, int nframes)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (nframes < 0 || nframes > RT_MAX_BATCH || (nframes > 0 && !d_uv)) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	for (int f = 0; f < RT_MAX_BATCH; ++f) ctx->frame_uv[f] = f < nframes ? d_uv[f] : nullptr;
+	ctx->frame_uv_count = nframes;
 	return RT_HIP_OK;
 }
 
@@ -633,6 +663,14 @@ int rt_hip_render_gbuffer_device(rt_hip_ctx* ctx, float fov, int width, int heig
 	RT_CHECK(check_ready(ctx));
 	if (width <= 0 || height <= 0 || !d_nrm_rgba || !d_pos_rgb) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
 	return rt_render_gbuffer(ctx, fov, width, height, d_nrm_rgba, d_pos_rgb);
+}
+
+int rt_hip_render_gbuffer_uv_device(rt_hip_ctx* ctx, float fov, int width, int height, float* d_nrm_rgba, float* d_pos_rgb,
+                                    float* d_uv)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !d_nrm_rgba || !d_pos_rgb || !d_uv) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	return rt_render_gbuffer(ctx, fov, width, height, d_nrm_rgba, d_pos_rgb, d_uv);
 }
 
 // ---- full frame --------------------------------------------------------------------------------

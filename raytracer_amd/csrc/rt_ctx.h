@@ -47,6 +47,11 @@ struct HostMesh {
 	size_t vert_offset;  // into the concatenated device vertex arrays
 };
 
+struct HostTexture {  // Material::texture, data/data.h:7-16
+	int w = 0, h = 0;
+	std::vector<uint32_t> texels;  // RGBA8 words, row 0 = bottom scanline
+};
+
 struct HostSphere {
 	float c[3];
 	float r;
@@ -64,6 +69,8 @@ struct SceneView {
 	const SphereRec* spheres;
 	const MaterialRec* materials;
 	const LightRec* lights;
+	const TexRec* tex;        // per material, or nullptr: no material of the scene is textured
+	const uint32_t* texels;   // RGBA8 pool of all textures
 	int num_tris;
 	int num_spheres;
 	int num_materials;
@@ -86,6 +93,7 @@ struct FrameSet {
 	const float* pos[RT_MAX_BATCH];
 	const float* nrm[RT_MAX_BATCH];
 	uint8_t* rgba[RT_MAX_BATCH];
+	const float* uv[RT_MAX_BATCH];  // level-0 texture coordinates (w*h x 2) or nullptr: (0,0); read only when the scene has textures
 	int nframes;
 	int per_frame;         // level-0 nodes per frame
 	const int* tile_list;  // owned tile ids (ty * tiles_x + tx), or nullptr: every 8x8 block of the frame
@@ -112,13 +120,17 @@ struct rt_hip_ctx {
 	std::vector<HostMesh> meshes;
 	std::vector<HostSphere> spheres;
 	std::vector<rt_material> materials;
+	std::vector<HostTexture> textures;                            // by material id (shorter than `materials` is fine)
+	bool any_texture = false;
+	const float* frame_uv[RT_MAX_BATCH] = {};                     // rt_hip_set_frame_texcoords_device
+	int frame_uv_count = 0;
 	std::vector<rt_light> lights;
 	bool scene_dirty = true;
 	bool sphere_rng_seeded = false;
 
 	// geometry in HBM
 	DevBuf d_verts, d_normals, d_texcoords, d_faces, d_mesh_of_tri, d_mesh_xf;  // inputs of the soup kernel
-	DevBuf d_tri_pos, d_tri_attr, d_tri_isect, d_tri_box, d_nodes, d_qnodes, d_spheres, d_materials, d_lights;
+	DevBuf d_tri_pos, d_tri_attr, d_tri_isect, d_tri_box, d_nodes, d_qnodes, d_spheres, d_materials, d_lights, d_tex, d_texels;
 	DevBuf d_morton, d_morton_tmp, d_order, d_order_tmp, d_hist, d_flags, d_parent_leaf, d_bounds, d_misc, d_ploc;
 	int num_tris = 0, num_nodes = 0, bvh_depth = 0, use_bvh = 0;
 	float bounds[6];
@@ -126,7 +138,7 @@ struct rt_hip_ctx {
 
 	// per-call scratch in HBM
 	DevBuf d_org, d_dir, d_hits, d_occ, d_in_a, d_in_b, d_records, d_offsets, d_keys, d_rank, d_counts;
-	DevBuf d_nodes_a, d_nodes_b, d_rays_q, d_ray_parent, d_accum, d_qcount, d_gate;
+	DevBuf d_nodes_a, d_nodes_b, d_rays_q, d_ray_parent, d_accum, d_qcount, d_gate, d_node_uv;
 	// pinned host staging
 	void* h_records = nullptr; size_t h_records_cap = 0;
 	void* h_offsets = nullptr; size_t h_offsets_cap = 0;
@@ -194,7 +206,7 @@ int rt_live_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rg
                   uint8_t* d_raypass, uint8_t* d_rgba, int* out_rays);
 int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, int h, int tile, const int* d_tile_list,
                          int ntiles, uint8_t* d_packed);
-int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb);
+int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb, float* d_uv = nullptr);
 int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
                     int rank, int nranks, uint8_t* d_rgba);
 int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,

@@ -103,6 +103,15 @@ struct MaterialRec {  // device copy of rt_material without the texture slot
 };
 static_assert(sizeof(MaterialRec) == 48, "material record");
 
+// Material::texture (data/data.h:25): one record per material beside the material table, texels of
+// all textures in one RGBA8 pool (little-endian words, row 0 = bottom scanline as FreeImage_GetBits
+// and glTexImage2D see it).  w == 0: the material has no texture.
+struct TexRec {
+	uint32_t offset;  // first texel in the pool
+	int w, h;
+	int pad;
+};
+
 struct LightRec {
 	float position[3];
 	float color[3];

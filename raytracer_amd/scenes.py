@@ -32,6 +32,7 @@ class Material:
     reflectivity: float = 0.0
     alpha: float = 0.0
     ior: float = 1.0
+    texture: object = None     # (h, w, 4) u8 RGBA, row 0 = bottom scanline (Texture, data/data.h:7-16), or None
 
 
 @dataclass

@@ -512,7 +512,7 @@ def test_render_tiles_batch_equals_single_frames(rt, oracle_cls, nranks, tile):
 
 
 # ---- the live (Gen-2) frame: select -> processRays -> raypass -> composite ------------
-def _oracle_live_frame(orc, sc, nr, po, interlace, phase, raypass):
+def _oracle_live_frame(orc, sc, nr, po, interlace, phase, raypass, uv=None):
     """Scene::draw from the G-buffer on, composed from the oracle's pieces (raypass updated in place)."""
     from oracle.pyoracle import RAY_DTYPE
     n = nr.shape[0]
@@ -533,6 +533,8 @@ def _oracle_live_frame(orc, sc, nr, po, interlace, phase, raypass):
     rec = np.zeros(int(cov.sum()), RAY_DTYPE)
     rec["position"] = po[cov]
     rec["normal"] = (nr[cov, :3].astype(np.float64) * 2.0 - 1.0).astype(np.float32)
+    if uv is not None:
+        rec["texcoord"] = uv[cov]                                    # the forward pass's interpolated outCoord
     shaded = orc.shade_records(rec, mid[cov])                       # (1 - refl) * direct
     refl = np.array([m.reflectivity for m in sc.materials], np.float32)[mid[cov]][:, None]
     col = refl * (raypass[cov].astype(np.float32) / np.float32(255)) + shaded
