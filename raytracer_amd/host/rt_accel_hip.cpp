@@ -18,6 +18,12 @@ void upload_materials(rt_hip_ctx* ctx, const std::vector<Material*>& mats)
 		memcpy(&table[i], mats[i], sizeof(rt_material));  // identical layout; Texture* rides in `texture`
 	}
 	rt_hip_set_materials(ctx, table.empty() ? 0 : &table[0], (int)table.size());
+	// Material::texture (data/data.h:25): the decoded image goes to the GPU with the table
+	for (size_t i = 0; i < mats.size(); ++i) {
+		const Texture* t = mats[i]->texture;
+		if (t && t->pixels && t->width && t->height)
+			rt_hip_set_texture(ctx, (int)i, t->pixels, (int)t->width, (int)t->height);
+	}
 }
 int add_mesh(rt_hip_ctx* ctx, Mesh* mesh, int material_id)
 {

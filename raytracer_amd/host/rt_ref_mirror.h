@@ -10,7 +10,12 @@ struct Vec3f { float v[3]; float& operator[](int i) { return v[i]; } const float
 struct Vec2f { float v[2]; };
 struct alignas(16) Mat4f { float m[16]; const float* data() const { return m; } };  // column-major, as Eigen::Matrix4f
 
-class Texture;
+class Texture {                 // data/data.h:7-16 (members only)
+	struct FIBITMAP* bitmap;
+public:
+	unsigned char* pixels;      // RGBA8, FreeImage_GetBits row order (row 0 = bottom), data/data.cpp:17-26
+	unsigned int width, height;
+};
 struct Material {               // data/data.h:18-26
 	Vec3f diffuse_color, specular_color;
 	float shininess, reflectivity, alpha, ior;
