@@ -162,16 +162,25 @@ def main():
             for f in range(nframes):
                 xchg.pack(f, tiles[f])
             xchg.exchange(frame)
+        elif xchg and os.environ.get("BENCH_XCHG") == "sync":   # collective between the steps instead of under the next one
+            xchg.render(gb_p, gb_n)
+            rays = g.last_frame_rays()
+            xchg.exchange(frame)
         elif xchg:
             xchg.render(gb_p, gb_n)       # ... written straight into the packed chunks: chunk f goes to rank f
             rays = g.last_frame_rays()
-            xchg.exchange(frame)          # one all-to-all (RCCL) + one unpack kernel: frame `rank` is complete here
+            xchg.finish(frame)            # the PREVIOUS step's all-to-all ran under this step's kernels: unpack -> its frame `rank` is complete
+            xchg.begin()                  # this step's all-to-all (RCCL, own stream); finished during the next step, or by drain()
         else:
             # the binding's un-fenced entry: the G-buffers were complete before the loop and the call itself
             # returns only after its last kernel, so the per-call torch-stream drain has nothing to wait for
             render_batch(g, gb_p, gb_n, W, H, 64, rank, world, tiles)
             rays = g.last_frame_rays()
         return rays
+
+    def drain():
+        if xchg:
+            xchg.finish(frame)            # the last step's exchange belongs to the timed region
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -181,12 +190,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     g.reset_stats()
     t0 = time.perf_counter()
     rays_rank = 0
     for _ in range(args.steps):
         rays_rank += step()
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
     st = g.stats()
@@ -259,6 +270,15 @@ def main():
                             "avg_launch_ms": round(clo_ms / max(clo_launches, 1), 4)}}
 
     # ---- CPU baseline on rank 0 (N = 1 only) ------------------------------------------------
+    # ---- N > 1 (untimed): the frame assembled from all ranks' tiles == the same frame shaded whole on this rank ----
+    tiles_verified = None
+    if xchg:
+        whole = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)
+        g.render_frame_device(gb_p[rank], gb_n[rank], W, H, whole)
+        ok = torch.tensor([1.0 if torch.equal(whole, frame) else 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        tiles_verified = bool(ok.item() == 1.0)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(scene, gb_n[0], gb_p[0], W, H, args.cpu_sample)
@@ -275,6 +295,8 @@ def main():
                        "rays_per_frame": round(total_rays / args.steps / nframes, 1),
                        "ms_per_frame": round(elapsed / args.steps * 1e3, 3),
                        "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"],
+                       **({"exchange": "all-to-all of packed tiles, overlapped with the next step" if os.environ.get("BENCH_XCHG") is None else os.environ["BENCH_XCHG"],
+                           "assembled_frames_equal_whole_frames": tiles_verified} if xchg else {}),
                        **({"photon_map": photon_info} if photon_info else {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -17,8 +17,12 @@ from .tiles import max_owned_tiles, owned_tiles
 
 
 class TileExchange:
-    """step(): this rank's tiles of the N frames, rendered straight into the send chunks (one wavefront,
-    packed layout), one all-to-all, one unpack kernel: frame `rank` is then complete in `d_frame_rgba`."""
+    """One step: render() this rank's tiles of the N frames straight into the send chunks (one wavefront,
+    packed layout), begin() the all-to-all, finish() = wait for it + one unpack kernel: frame `rank` is
+    then complete in `d_frame_rgba`.  Send and receive buffers are double-buffered, so a caller may
+    render step k+1 between begin() and finish() of step k: the collective (RCCL's own stream and a few
+    workgroups) then runs under the next step's trace kernels instead of between steps.  exchange() is
+    begin() + finish() back to back."""
 
     def __init__(self, ctx, width, height, tile, rank, world, device, group=None):
         self.ctx, self.w, self.h, self.tile, self.rank, self.world, self.group = ctx, width, height, tile, rank, world, group
@@ -26,16 +30,19 @@ class TileExchange:
         self.ntiles = [int(len(l)) for l in lists]
         self.chunk = max_owned_tiles(width, height, tile, world) * tile * tile * 4   # bytes, equal splits
         self.d_lists = [torch.from_numpy(np.ascontiguousarray(l)).to(device) for l in lists]
-        self.send = torch.zeros(world * self.chunk, dtype=torch.uint8, device=device)   # zero once: padding is never written
-        self.recv = torch.zeros(world * self.chunk, dtype=torch.uint8, device=device)
+        # zeroed once: the padding of a chunk is never written
+        self.send = [torch.zeros(world * self.chunk, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.recv = [torch.zeros(world * self.chunk, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.cur = 0          # the buffer pair render() / pack() fill and begin() sends
+        self.pending = None   # (work handle, buffer index, host staging) of the all-to-all in flight
 
     def chunks(self):
         c = self.chunk
-        return [self.send[f * c:(f + 1) * c] for f in range(self.world)]
+        return [self.send[self.cur][f * c:(f + 1) * c] for f in range(self.world)]
 
     def render(self, d_pos_list, d_nrm_list):
         """Shade this rank's tiles of every frame of the step into the send chunks (chunk f -> rank f)."""
-        # un-fenced entry: the call returns after its last kernel, and exchange() orders the streams around the collective
+        # un-fenced entry: the call returns after its last kernel, and begin() / finish() order the streams around the collective
         type(self.ctx).render_tiles_packed_device.__wrapped__(self.ctx, d_pos_list, d_nrm_list, self.w, self.h, self.tile, self.rank,
                                                               self.world, self.chunks())
 
@@ -43,16 +50,36 @@ class TileExchange:
         """Alternative to render(): pack this rank's tiles of a full-size image into chunk `frame_index`."""
         c = self.chunk
         self.ctx.pack_tiles_device(d_tiles_rgba, self.w, self.h, self.tile, self.d_lists[self.rank], self.ntiles[self.rank],
-                                   self.send[frame_index * c:(frame_index + 1) * c])
+                                   self.send[self.cur][frame_index * c:(frame_index + 1) * c])
+
+    def begin(self):
+        """Start the all-to-all of the chunks just rendered; at most one may be in flight."""
+        if self.pending is not None:
+            raise RuntimeError("TileExchange.begin(): finish() the exchange in flight first")
+        b = self.cur
+        torch.cuda.current_stream().synchronize()                 # nothing of torch's pending on send / recv
+        if dist.get_backend(self.group) == "gloo":                # rehearsal on a box without RCCL peers: stage through the host
+            host_recv = torch.zeros(self.recv[b].shape, dtype=torch.uint8)
+            work = dist.all_to_all_single(host_recv, self.send[b].cpu(), group=self.group, async_op=True)
+        else:
+            host_recv = None
+            work = dist.all_to_all_single(self.recv[b], self.send[b], group=self.group, async_op=True)
+        self.pending = (work, b, host_recv)
+        self.cur = b ^ 1
+
+    def finish(self, d_frame_rgba):
+        """Wait for the all-to-all begun last and assemble frame `rank` in d_frame_rgba (no-op if none is in flight)."""
+        if self.pending is None:
+            return
+        work, b, host_recv = self.pending
+        self.pending = None
+        work.wait()
+        if host_recv is not None:
+            self.recv[b].copy_(host_recv)
+        torch.cuda.current_stream().synchronize()                 # chunks landed before the context's stream reads them
+        self.ctx.unpack_chunks_device(self.recv[b], self.chunk, self.w, self.h, self.tile, self.world, d_frame_rgba)
 
     def exchange(self, d_frame_rgba):
         """All-to-all of the packed chunks, then assemble frame `rank` in d_frame_rgba."""
-        torch.cuda.current_stream().synchronize()                 # nothing of torch's pending on send / recv
-        if dist.get_backend(self.group) == "gloo":                # rehearsal on a box without RCCL peers: stage through the host
-            recv = torch.zeros(self.recv.shape, dtype=torch.uint8)
-            dist.all_to_all_single(recv, self.send.cpu(), group=self.group)
-            self.recv.copy_(recv)
-        else:
-            dist.all_to_all_single(self.recv, self.send, group=self.group)
-        torch.cuda.current_stream().synchronize()                 # chunks landed before the context's stream reads them
-        self.ctx.unpack_chunks_device(self.recv, self.chunk, self.w, self.h, self.tile, self.world, d_frame_rgba)
+        self.begin()
+        self.finish(d_frame_rgba)
