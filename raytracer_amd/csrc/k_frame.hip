@@ -1507,7 +1507,6 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 	std::vector<int> count(bounces + 1, 0);
 	std::vector<size_t> geo_off(bounces + 1, 0);
 	count[0] = npix;
-	size_t total_nodes = 0;
 	// reserve level 0 now, deeper levels as they appear (one DevBuf, offsets in nodes)
 	auto ensure_nodes = [&](size_t nodes) -> int {
 		RT_CHECK(ctx->d_nodes_a.reserve(nodes * sizeof(NodeGeo)));
@@ -1532,7 +1531,6 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 	int active0 = 0;
 	RT_HIP_CHECK(hipMemcpyAsync(&active0, qcount + 8, 4, hipMemcpyDeviceToHost, st));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
-	const bool shadow_rays = !ctx->cfg.use_photon_map && ctx->cfg.do_shadows && sv.num_lights > 0;
 
 	int64_t rays = 0;
 	int levels = 0;
@@ -1540,7 +1538,6 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		const int n = count[L];
 		if (n == 0) break;
 		levels = L + 1;
-		total_nodes = geo_off[L] + (size_t)n;
 		const bool recurse = (L + 1 < bounces);
 		// (re)fetch base pointers: reserve() may have moved the buffers
 		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + geo_off[L];
@@ -1636,8 +1633,6 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		}
 		count[L + 1] = h_counts[1];
 	}
-	(void)total_nodes;
-	(void)spheres;
 
 	// shadow-ray count: every active node of every shaded level issues num_lights rays
 	// bottom-up combine
@@ -1656,7 +1651,6 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 	RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
 	ctx->stats.frame_ms += ms;
 	ctx->stats.frames += 1;
-	(void)shadow_rays;
 	ctx->last_frame_rays = rays;
 	// stash per-level counts for the census
 	ctx->last_count = levels;
