@@ -231,6 +231,71 @@ __device__ __forceinline__ void for_each_neighbour(const GridDesc& gd, const uin
 		}
 }
 
+// Photons in the cells for_each_neighbour would visit (an upper bound of the photons within rho).
+__device__ __forceinline__ uint32_t cube_population(const GridDesc& gd, const uint32_t* __restrict__ cell_start, f3 P, float rho)
+{
+	rho = rho * 1.0001f + 1e-30f;
+	int x0 = cell_coord(P.x - rho, gd.mn[0], gd.inv_cell, gd.dim[0]), x1 = cell_coord(P.x + rho, gd.mn[0], gd.inv_cell, gd.dim[0]);
+	int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
+	int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
+	uint32_t total = 0;
+	for (int z = z0; z <= z1; ++z)
+		for (int y = y0; y <= y1; ++y) {
+			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
+			total += cell_start[row + x1 + 1] - cell_start[row + x0];
+		}
+	return total;
+}
+
+// The same walk with the 64 lanes of a wave striding over every span (P and rho are wave-uniform):
+// f(slot, l2, active) runs in uniform control flow, `active` false in the padding of a span's last chunk.
+template <typename F>
+__device__ __forceinline__ void for_each_neighbour_wave(const GridDesc& gd, const uint32_t* __restrict__ cell_start,
+                                                        const float4* __restrict__ pos, f3 P, float rho, F f)
+{
+	rho = rho * 1.0001f + 1e-30f;
+	int x0 = cell_coord(P.x - rho, gd.mn[0], gd.inv_cell, gd.dim[0]), x1 = cell_coord(P.x + rho, gd.mn[0], gd.inv_cell, gd.dim[0]);
+	int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
+	int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
+	const uint32_t lane = (uint32_t)lane_id();
+	for (int z = z0; z <= z1; ++z)
+		for (int y = y0; y <= y1; ++y) {
+			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
+			const uint32_t s0 = cell_start[row + x0], s1 = cell_start[row + x1 + 1];
+			uint32_t s = s0;
+			for (; s + 128 <= s1; s += 128) {  // two coalesced 1-KB loads in flight
+				const float4 qa = pos[s + lane], qb = pos[s + 64 + lane];
+				f3 da = mk3(qa.x, qa.y, qa.z) - P, db = mk3(qb.x, qb.y, qb.z) - P;
+				f(s + lane, dot3(da, da), true);
+				f(s + 64 + lane, dot3(db, db), true);
+			}
+			for (; s < s1; s += 64) {
+				const uint32_t k = s + lane;
+				const bool act = k < s1;
+				float4 q = make_float4(0, 0, 0, 0);
+				if (act) q = pos[k];
+				f3 d = mk3(q.x, q.y, q.z) - P;
+				f(k, dot3(d, d), act);
+			}
+		}
+}
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+	return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v)
+{
+	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+	return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+	for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+	return v;
+}
+
 // PhotonMap::radiance_estimate (rt_photon_map.cpp:149-208), one lane per shading point.
 //   pass 1   all photons within `radius`: their number, max_dist2 over ALL of them (:159-169), and a
 //            64-bin histogram of the squared distance over [0, r^2)
@@ -261,13 +326,31 @@ __global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uin
                                                           const float4* __restrict__ payload, int64_t nph,
                                                           const float* __restrict__ qpos, const float* __restrict__ qnrm,
                                                           int npts, int count, float radius, GatherConst gc,
-                                                          float* __restrict__ rgb)
+                                                          float* __restrict__ rgb, uint32_t heavy_threshold,
+                                                          int* __restrict__ heavy_queue, int* __restrict__ heavy_count)
 {
 	__shared__ uint32_t s_hist[SEL_BINS * GBLOCK];  // doubles as the candidate list (SEL_LIST <= SEL_BINS)
 	uint32_t* hist = s_hist + threadIdx.x;
 	int i = blockIdx.x * GBLOCK + threadIdx.x;
-	if (i >= npts) return;
-	f3 P = ld3(qpos + 3 * (size_t)i), N = ld3(qnrm + 3 * (size_t)i);
+	const bool valid = i < npts;
+	f3 P = mk3(0, 0, 0), N = mk3(0, 0, 0);
+	if (valid) { P = ld3(qpos + 3 * (size_t)i); N = ld3(qnrm + 3 * (size_t)i); }
+	// Load balance: the number of photons around a point spans five orders of magnitude (C5: median 0,
+	// 99th percentile 7e4, maximum 4e5 within the radius), and a lane walks its neighbourhood alone.  A
+	// point whose cube holds more than `heavy_threshold` photons is handed to k_photon_gather_wave, which
+	// puts a whole wave on it; one queue slot per point, one atomic per wave.
+	bool heavy = false;
+	if (valid && nph > 0) heavy = cube_population(gd, cell_start, P, radius) > heavy_threshold;
+	{
+		const uint64_t hm = __ballot(heavy);
+		if (hm) {
+			int base = 0;
+			if (lane_id() == 0) base = atomicAdd(heavy_count, (int)__popcll(hm));
+			base = __shfl(base, 0);
+			if (heavy) heavy_queue[base + (int)__popcll(hm & lanemask_lt())] = i;
+		}
+	}
+	if (!valid || heavy) return;
 	const float r2 = radius * radius;
 	SelLevel lv[SEL_LEVELS];
 	int nlv = 0;
@@ -384,6 +467,180 @@ __global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uin
 	// result / (2*PI*max_dist2): 0 * (1/0) = NaN when nothing is in range, as the reference (:204)
 	result = div3(result, gc.two_pi * max_dist2);
 	st3(rgb + 3 * (size_t)i, result);
+}
+
+// The same estimate with ONE WAVE per shading point (the points k_photon_gather queued as heavy): the
+// lanes stride over the photon spans with coalesced loads, the histogram and the candidate list are
+// the wave's (LDS atomics), and the control flow of the selection is wave-uniform.  Same passes, same
+// bins, same tie rule (photons at the k-th distance are taken in walk order) as the per-lane kernel;
+// only the order of the floating-point sum differs (lane partial sums, then a butterfly).
+__global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
+                                                           const float4* __restrict__ pos,
+                                                           const float4* __restrict__ payload, int64_t nph,
+                                                           const float* __restrict__ qpos, const float* __restrict__ qnrm,
+                                                           const int* __restrict__ heavy_queue,
+                                                           const int* __restrict__ heavy_count, int count, float radius,
+                                                           GatherConst gc, float* __restrict__ rgb)
+{
+	__shared__ uint32_t s_hist[SEL_BINS];
+	__shared__ uint32_t s_list[SEL_LIST];
+	__shared__ uint32_t s_m, s_tau;
+	__shared__ int s_take;
+	static_assert(SEL_BINS == 64, "one histogram bin per lane");
+	const int lane = lane_id();
+	const int nheavy = *heavy_count;
+	const float r2 = radius * radius;
+	for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
+		const int i = __builtin_amdgcn_readfirstlane(heavy_queue[h]);
+		f3 P, N;
+		P.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 0])));
+		P.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 1])));
+		P.z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 2])));
+		N = ld3(qnrm + 3 * (size_t)i);
+		SelLevel lv[SEL_LEVELS];
+		int nlv = 0;
+		auto in_levels = [&](float l2, int upto) {
+			bool ok = l2 < r2;
+			for (int k = 0; k < SEL_LEVELS; ++k)
+				if (k < upto) ok = ok && sel_bin(l2, lv[k].lo, lv[k].scale) == lv[k].bin;
+			return ok;
+		};
+		// pass 1: the number of photons within the radius and max_dist2 over all of them -- nothing else, this
+		// is the one pass that has to read every photon of the cube
+		int nc_l = 0;
+		float mx_l = 0.0f;
+		for_each_neighbour_wave(gd, cell_start, pos, P, radius, [&](uint32_t, float l2, bool act) {
+			if (act && l2 < r2) { ++nc_l; mx_l = fmaxf(mx_l, l2); }
+		});
+		const int nc = wave_sum_i(nc_l);
+		const float max_dist2 = wave_max_f(mx_l);
+		uint32_t tau = 0xFFFFFFFFu;
+		int take_equal = 0x7fffffff;
+		float rho_sel = radius;
+		if (nc > count) {
+			// level-0 histogram.  Photons lie on surfaces, so their number grows like l2: the count-th is
+			// expected near r2 * count / nc.  The histogram first covers [0, 4x that) and reads only the
+			// cells within its upper edge; if the count-th is not below the edge after all (its bin would
+			// be the top one, whose population the short walk does not know), the full range is taken.
+			float top = fminf(r2, r2 * (4.0f * (float)count / (float)nc));
+			for (;;) {
+				lv[0].lo = 0.0f; lv[0].scale = (float)SEL_BINS / top; lv[0].bin = 0;
+				__syncthreads();  // earlier readers are done with the shared state
+				s_hist[lane] = 0u;
+				__syncthreads();
+				const float rho0 = top < r2 ? fminf(radius, rt_sqrtf(top) * 1.001f) : radius;
+				for_each_neighbour_wave(gd, cell_start, pos, P, rho0, [&](uint32_t, float l2, bool act) {
+					if (act && l2 < r2) atomicAdd(&s_hist[sel_bin(l2, lv[0].lo, lv[0].scale)], 1u);
+				});
+				__syncthreads();
+				if (!(top < r2)) break;
+				int below = 0;
+				for (int b = 0; b < SEL_BINS - 1; ++b) below += (int)s_hist[b];
+				if (below >= count) break;
+				top = r2;
+			}
+			int need = count;
+			int pop = nc;
+			float hi_edge = r2;
+			for (;;) {
+				int b = 0, cum = 0;
+				for (; b < SEL_BINS - 1; ++b) {
+					int hh = (int)s_hist[b];
+					if (cum + hh >= need) break;
+					cum += hh;
+				}
+				need -= cum;
+				pop = (int)s_hist[b];
+				const float width = 1.0f / lv[nlv].scale;
+				const float lo_edge = lv[nlv].lo + (float)b * width;
+				if (b < SEL_BINS - 1) hi_edge = fminf(hi_edge, lo_edge + width * 1.001f + fabsf(lo_edge) * 4e-6f);
+				lv[nlv].bin = b;
+				++nlv;
+				rho_sel = fminf(radius, rt_sqrtf(hi_edge) * 1.001f);
+				if (pop <= SEL_LIST || nlv == SEL_LEVELS || !(width > 0.0f)) break;
+				lv[nlv].lo = lo_edge; lv[nlv].scale = (float)SEL_BINS / width; lv[nlv].bin = 0;
+				__syncthreads();
+				s_hist[lane] = 0u;
+				__syncthreads();
+				const int upto = nlv;
+				for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
+					if (act && in_levels(l2, upto)) atomicAdd(&s_hist[sel_bin(l2, lv[upto].lo, lv[upto].scale)], 1u);
+				});
+				__syncthreads();
+			}
+			if (pop <= SEL_LIST) {
+				const int upto = nlv;
+				if (lane == 0) { s_m = 0u; s_tau = 0xFFFFFFFFu; s_take = 0x7fffffff; }
+				__syncthreads();
+				for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
+					if (act && in_levels(l2, upto)) {
+						uint32_t slot = atomicAdd(&s_m, 1u);
+						if (slot < (uint32_t)SEL_LIST) s_list[slot] = __float_as_uint(l2);
+					}
+				});
+				__syncthreads();
+				const int m = (int)min(s_m, (uint32_t)SEL_LIST);
+				if (lane < m) {
+					const uint32_t v = s_list[lane];
+					int lt = 0, le = 0;
+					for (int c = 0; c < m; ++c) {
+						const uint32_t x = s_list[c];
+						lt += x < v; le += x <= v;
+					}
+					// lanes holding equal values agree on (tau, take_equal): any of them may publish it
+					if (lt < need && need <= le) { s_tau = v; s_take = need - lt; }
+				}
+				__syncthreads();
+				tau = s_tau; take_equal = s_take;
+			} else {
+				const int upto = nlv;
+				uint32_t lo = 0u, hi = __float_as_uint(r2);
+				while (lo < hi) {
+					uint32_t mid = lo + ((hi - lo) >> 1);
+					int c = 0;
+					for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
+						if (act && in_levels(l2, upto) && __float_as_uint(l2) <= mid) ++c;
+					});
+					c = wave_sum_i(c);
+					if (c >= need) hi = mid; else lo = mid + 1;
+				}
+				tau = lo;
+				int less = 0;
+				for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
+					if (act && in_levels(l2, upto) && __float_as_uint(l2) < tau) ++less;
+				});
+				take_equal = need - wave_sum_i(less);
+			}
+		}
+		// pass 3
+		f3 result = mk3(0, 0, 0);
+		if (nc > 0) {
+			const float denom2 = 2.0f * max_dist2;
+			int taken = 0;  // photons at tau already taken, in walk order (wave-uniform)
+			for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t s, float l2, bool act) {
+				const uint32_t b = __float_as_uint(l2);
+				const bool inr = act && l2 < r2;
+				const bool eq = inr && b == tau;
+				const uint64_t em = __ballot(eq);
+				bool sel = inr && b < tau;
+				if (eq) sel = (long long)taken + (long long)__popcll(em & lanemask_lt()) < (long long)take_equal;
+				// saturating: take_equal is INT_MAX when every photon within the radius is taken
+				taken = (int)min((long long)taken + (long long)__popcll(em), (long long)0x7fffffff);
+				if (!sel) return;
+				float w = 1.0f - powf(gc.e, -gc.beta * (l2 / denom2));
+				w *= gc.gauss_denom;
+				w = gc.alpha * (1.0f - w);
+				float4 a = payload[2 * (size_t)s], c = payload[2 * (size_t)s + 1];
+				f3 energy = mk3(a.x, a.y, a.z), dir = mk3(a.w, c.x, c.y);
+				float brdf = dot3(N, neg3(dir));
+				brdf = fminf(fmaxf(brdf, 0.0f), 1.0f);
+				result = result + (energy * brdf) * w;
+			});
+			result.x = wave_sum_f(result.x); result.y = wave_sum_f(result.y); result.z = wave_sum_f(result.z);
+		}
+		result = div3(result, gc.two_pi * max_dist2);
+		if (lane == 0) st3(rgb + 3 * (size_t)i, result);
+	}
 }
 
 float ord2f(uint32_t o)
@@ -503,9 +760,26 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	gc.alpha = ALPHA; gc.beta = BETA; gc.e = E;
 	gc.gauss_denom = 1 / (1 - powf(E, -BETA));
 	gc.two_pi = 2 * PI;
+	// points with more than `heavy` photons in their cube go to the wave-per-point kernel (queue and count stay
+	// on the device).  RT_HIP_GATHER_HEAVY overrides the threshold (0: every point with a photon nearby takes
+	// the wave kernel; a huge value: none does) -- the parity tests run both extremes.
+	uint32_t heavy = 1024;
+	if (const char* e = getenv("RT_HIP_GATHER_HEAVY")) heavy = (uint32_t)strtoul(e, nullptr, 10);
+	RT_CHECK(ctx->d_heavy.reserve(((size_t)npts + 16) * sizeof(int)));
+	int* heavy_count = ctx->d_heavy.as<int>();
+	int* heavy_queue = heavy_count + 16;
+	RT_HIP_CHECK(hipMemsetAsync(heavy_count, 0, sizeof(int), ctx->stream));
 	hipLaunchKernelGGL(k_photon_gather, dim3(nblocks(npts, GBLOCK)), dim3(GBLOCK), 0, ctx->stream, gd,
 	                   ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(),
-	                   ctx->num_photons, d_pos, d_nrm, npts, count, radius, gc, d_rgb);
+	                   ctx->num_photons, d_pos, d_nrm, npts, count, radius, gc, d_rgb, heavy, heavy_queue, heavy_count);
 	RT_HIP_CHECK(hipGetLastError());
+	if (ctx->num_photons > 0) {
+		// one wave per queued point, grid-stride over a queue whose length only the device knows
+		const int waves = std::min(npts, 64 * 1024);
+		hipLaunchKernelGGL(k_photon_gather_wave, dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
+		                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->num_photons, d_pos, d_nrm,
+		                   heavy_queue, heavy_count, count, radius, gc, d_rgb);
+		RT_HIP_CHECK(hipGetLastError());
+	}
 	return RT_HIP_OK;
 }

@@ -145,7 +145,7 @@ struct rt_hip_ctx {
 	void* h_small = nullptr;   // 4 KiB pinned scratch for counters
 
 	// photon map
-	DevBuf d_photons, d_photon_cell, d_photon_sorted, d_cell_start, d_photon_tmp;
+	DevBuf d_photons, d_photon_cell, d_photon_sorted, d_cell_start, d_photon_tmp, d_heavy;
 	int64_t num_photons = 0;
 	float photon_cell = 1.0f;
 	float photon_grid_min[3];

@@ -55,9 +55,14 @@ def test_emission_is_shard_invariant(oracle_cls):
     g.close()
 
 
+@pytest.mark.parametrize("heavy", [None, "0", "4000000000"], ids=["default-split", "all-wave", "all-lane"])
 @pytest.mark.parametrize("count,radius", [(100, 1.0), (50, 3.0), (7, 0.5)])
-def test_gather_matches_oracle(oracle_cls, count, radius):
+def test_gather_matches_oracle(oracle_cls, count, radius, heavy, monkeypatch):
+    """Both gather kernels against the oracle: by default a point goes to the wave-per-point kernel when its
+    cube holds more than 1024 photons; RT_HIP_GATHER_HEAVY = 0 / huge sends every point one way."""
     import raytracer_amd as rt
+    if heavy is not None:
+        monkeypatch.setenv("RT_HIP_GATHER_HEAVY", heavy)
     sc = scenes.cornell()
     orc = oracle_cls(sc)
     ph = orc.photon_generate(6000, geometry=0, rng=1, seed=42)
