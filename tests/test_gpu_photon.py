@@ -85,6 +85,30 @@ def test_gather_matches_oracle(oracle_cls, count, radius, heavy, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("heavy", ["0", "4000000000"], ids=["all-wave", "all-lane"])
+def test_gather_ties_at_the_kth_distance(oracle_cls, heavy, monkeypatch):
+    """Every photon stored three times: the k-th distance is shared by photons of which only some may be taken
+    (k = 100 is not a multiple of 3).  The copies are identical, so whichever the reference's unstable sort keeps,
+    the sum is the same; both kernels must take exactly k."""
+    import raytracer_amd as rt
+    monkeypatch.setenv("RT_HIP_GATHER_HEAVY", heavy)
+    sc = scenes.cornell()
+    orc = oracle_cls(sc)
+    ph = np.repeat(orc.photon_generate(3000, geometry=0, rng=1, seed=5), 3, axis=0)
+    nr, po = orc.software_gbuffer(48, 36)
+    pos, nrm, _ = orc.gbuffer_select(nr, po)
+    orc.photon_set(ph)
+    exp = orc.radiance_estimate(pos, nrm, 100, 1.5)
+    g = rt.RtHip(sc, semantics="array", photon_radius=1.5)
+    g.photon_set(ph)
+    got = g.radiance_estimate(pos, nrm, 100, 1.5)
+    ok = ~np.isnan(exp)
+    np.testing.assert_array_equal(np.isnan(exp), np.isnan(got))
+    assert ok.mean() > 0.5
+    np.testing.assert_allclose(got[ok], exp[ok], rtol=2e-5, atol=1e-9)
+    g.close()
+
+
 def test_gather_without_photons_is_nan(oracle_cls):
     import raytracer_amd as rt
     sc = scenes.cornell()
