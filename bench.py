@@ -67,6 +67,9 @@ def parse_args():
                     help="C5: photons per light (0 = off).  The sharded photon pass (emit -> RCCL all-gather -> grid) runs once, "
                          "untimed by `value` and reported as config.photon_pass_ms; frames then shade with radiance_estimate "
                          "instead of shadow rays")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="N = 1 only: frames in flight = contexts (each its own stream) fed from as many host threads; the "
+                         "default 1 keeps the kernels of a frame alone on the GPU, which is what the roofline object measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="G-buffer texels fed to the CPU baseline (0 = auto)")
     return ap.parse_args()
@@ -188,15 +191,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    # --inflight M: M - 1 further contexts (scene and BVH replicated, own stream, own output), one host thread each;
+    # step k goes to context k % M.  The frames overlap on the GPU: the tail of one frame's kernels and the host's
+    # per-frame work disappear under the other frame's kernels.
+    inflight = max(1, args.inflight) if world == 1 and args.photons == 0 else 1
+    extra = []
+    for _ in range(inflight - 1):
+        ge = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_PLOC if args.accel == "ploc" else rt.ACCEL_LBVH, device=dev_index,
+                      profile=0, bounces=2, do_shadows=1, shadow_t_max=shadow_t_max, seed=42)
+        extra.append((ge, [torch.zeros(npix * 4, dtype=torch.uint8, device=dev)]))
+
+    def run_steps(count):
+        if not extra:
+            return sum(step() for _ in range(count))
+        import threading
+        rays = [0] * inflight
+
+        def worker(t):
+            ctx, out = (g, tiles) if t == 0 else extra[t - 1]
+            for _ in range(t, count, inflight):
+                render_batch(ctx, gb_p, gb_n, W, H, 64, rank, world, out)
+                rays[t] += ctx.last_frame_rays()
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(inflight)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return sum(rays)
+
+    run_steps(args.warmup)
     drain()
     fence()
     g.reset_stats()
     t0 = time.perf_counter()
-    rays_rank = 0
-    for _ in range(args.steps):
-        rays_rank += step()
+    rays_rank = run_steps(args.steps)
     drain()
     fence()
     elapsed = time.perf_counter() - t0
@@ -292,6 +320,7 @@ def main():
             "config": {"workload": args.workload + ("+photons" if args.photons > 0 else ""), "scene": scene.name, "triangles": scene.num_tris, "width": W, "height": H,
                        "frames_per_step": nframes, "tile": 64, "bounces": 2, "lights": len(scene.lights),
                        "shadows": args.shadow_mode, "accel": args.accel, "parallelism": "tiles x%d" % world,
+                       **({"frames_in_flight": inflight} if inflight > 1 else {}),
                        "rays_per_frame": round(total_rays / args.steps / nframes, 1),
                        "ms_per_frame": round(elapsed / args.steps * 1e3, 3),
                        "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"],
