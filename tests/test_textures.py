@@ -203,3 +203,23 @@ def test_textured_live_shading(rt, oracle_cls):
     d_img = np.abs(got[cov].astype(int) - exp[cov].astype(int)).max(1)
     assert (d_rp_diff > 1).mean() <= 1e-3 and (d_img > 1).mean() <= 1e-3, ((d_rp_diff > 1).mean(), (d_img > 1).mean())
     g.close()
+
+
+@pytest.mark.gpu
+def test_texture_api_errors(rt):
+    torch = _torch()
+    sc = textured_cornell()
+    g = rt.RtHip(sc, semantics="array")
+    tex = _texture(4, 4, 9)
+    with pytest.raises(rt.RtHipError):
+        g.set_texture(len(sc.materials), tex)                     # material out of range
+    with pytest.raises(rt.RtHipError):
+        g.set_texture(-1, tex)
+    with pytest.raises(ValueError):
+        g.set_texture(0, tex[..., :3])                            # not RGBA
+    uv = torch.zeros(8, dtype=torch.float32, device="cuda")
+    with pytest.raises(rt.RtHipError):
+        g.set_frame_texcoords_device([uv] * 17)                   # more planes than a batch holds
+    g.set_frame_texcoords_device([uv] * 16)
+    g.set_frame_texcoords_device([])
+    g.close()
