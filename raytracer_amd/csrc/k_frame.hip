@@ -33,6 +33,12 @@ struct __attribute__((aligned(16))) NodeGeo {   // 48 B
 	float I[3];
 	int branch;    // 0 reflection child, 1 refraction child
 };
+// Sync-free frame driver: a node's shadow mask word also says which children it has (set by
+// k_make_children), so that NodeShade needs no zero-initialisation: k_combine reads the colour a child
+// returned only where that child exists.  Lights therefore use bits [0, 30).
+constexpr unsigned int CHILD_REFL_BIT = 1u << 30, CHILD_REFR_BIT = 1u << 31;
+constexpr int FRAME_ASYNC_MAX_LIGHTS = 30;
+
 struct __attribute__((aligned(16))) NodeShade { // 48 B
 	float F[3];    // shadow * light
 	float pad0;
@@ -446,7 +452,7 @@ __device__ __forceinline__ int level0_pixel(const FrameSet& fs, int jj, int w, i
 
 __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs, int w, int h, int n0, int tile,
                                                       int rank, int nranks, int recurse, NodeGeo* __restrict__ geo,
-                                                      NodeShade* __restrict__ shade, int* __restrict__ gate,
+                                                      int* __restrict__ gate,
                                                       unsigned int* __restrict__ occl, float* __restrict__ q_org,
                                                       float* __restrict__ q_dir, int* __restrict__ q_parent,
                                                       int* __restrict__ q_count, int* __restrict__ active_count,
@@ -482,12 +488,8 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
 		g.parent = i < 0 ? -1 : (fs.packed ? f * fs.per_frame + slot : f * (w * h) + i);
 		g.material = mat; g.branch = 0;
 		geo[j] = g;
-		NodeShade s;
-		s.pad0 = s.pad1 = s.pad2 = 0;
-		st3(s.F, mk3(0, 0, 0)); st3(s.refc, mk3(0, 0, 0)); st3(s.refrc, mk3(0, 0, 0));
-		shade[j] = s;
 		gate[j] = active ? mat : -1;
-		if (occl) occl[j] = 0u;
+		occl[j] = 0u;  // shadow mask + child flags; NodeShade stays unwritten until a child returns a colour
 		if (node_uv) {  // textured scenes only
 			const float* __restrict__ uvp = fs.uv[f];
 			const bool have = uvp && i >= 0;
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, co
 	f3 V = mk3(0, 0, 0), R = mk3(0, 0, 0);
 	if (i < n) {
 		const NodeGeo g = geo[i];
-		NodeShade s;
+		NodeShade s;  // written only when the light term is evaluated here (defer_light == 0)
 		s.pad0 = s.pad1 = s.pad2 = 0;
 		st3(s.refc, mk3(0, 0, 0)); st3(s.refrc, mk3(0, 0, 0));
 		if (g.material >= 0) {
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, co
 			st3(s.F, mk3(0, 0, 0));
 			gate[i] = -1;
 		}
-		shade[i] = s;
+		if (!defer_light) shade[i] = s;
 	}
 	// wave ballots + one atomic per workgroup
 	int slot = block_compact_slot(emit, q_count);
@@ -721,7 +723,8 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
                                                          unsigned int* __restrict__ child_occl,
                                                          int* __restrict__ child_count, int child_capacity,
                                                          int* __restrict__ overflow, const Hit* __restrict__ tc_hits,
-                                                         float* __restrict__ child_uv)
+                                                         float* __restrict__ child_uv,
+                                                         unsigned int* __restrict__ parent_flags)
 {
 	nq = dev_count(nq, n_ptr);
 	int i = blockIdx.x * CBLOCK + threadIdx.x;
@@ -748,6 +751,7 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
 		g.branch = branch;
 		child_geo[slot] = g;
 		if (child_occl) child_occl[slot] = 0u;
+		if (parent_flags) atomicOr(&parent_flags[g.parent], branch == 0 ? CHILD_REFL_BIT : CHILD_REFR_BIT);
 		if (child_uv) { child_uv[2 * (size_t)slot] = tc[0]; child_uv[2 * (size_t)slot + 1] = tc[1]; }
 	}
 }
@@ -770,7 +774,15 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 	f3 col = mk3(0, 0, 0);
 	if (g.material >= 0) {
 		const MaterialRec m = sv.materials[g.material];
-		const NodeShade s = shade[i];
+		NodeShade s;
+		const unsigned int oc = (lit && occl) ? occl[i] : 0u;
+		if (lit) {  // sync-free driver: a child's colour exists only where the flag says so
+			st3(s.F, mk3(0, 0, 0));
+			st3(s.refc, (oc & CHILD_REFL_BIT) ? ld3(shade[i].refc) : mk3(0, 0, 0));
+			st3(s.refrc, (oc & CHILD_REFR_BIT) ? ld3(shade[i].refrc) : mk3(0, 0, 0));
+		} else {
+			s = shade[i];
+		}
 		float ref = m.reflectivity, alpha = m.alpha;
 		float kd = (float)(1.0 - (double)ref - (double)alpha);
 		f3 diff = ld3(m.diffuse);
@@ -781,7 +793,7 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 		f3 mix = (diff * kd + ld3(s.refc) * ref) + ld3(s.refrc) * alpha;
 		f3 F = ld3(s.F);
 		if (lit) {  // deferred light_color(): the level's shadow rays have landed by now
-			float f = light_factor(sv, ld3(g.V), ld3(g.N), occl ? occl[i] : 0u);
+			float f = light_factor(sv, ld3(g.V), ld3(g.N), oc);
 			F = mk3(f, f, f);
 		}
 		col = mk3(F.x * mix.x, F.y * mix.y, F.z * mix.z);
@@ -1311,7 +1323,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	// hits, Q9); launch B = refraction queue + the shadow rays of the other lights; children.  The
 	// light term needs all shadow rays of the level, so it is evaluated in k_combine at the end.
 	const bool fuse = shadows && !(sv.num_spheres > 0 && sv.num_tris == 0);
-	if (shadows) RT_CHECK(ctx->d_occ.reserve((size_t)off[bounces] * 4));
+	RT_CHECK(ctx->d_occ.reserve((size_t)off[bounces] * 4));  // shadow masks and child flags
 	auto shadow_launch = [&](const NodeGeo* geo, int n, const int* n_ptr, int lo, int hi, unsigned int* occl,
 	                         const int* q_count) -> int {
 		FusedQueue fq{};
@@ -1344,11 +1356,11 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + off[L];
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
 		int* gate = ctx->d_gate.as<int>() + off[L];
-		unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
+		unsigned int* occl = ctx->d_occ.as<unsigned int>() + off[L];
 		if (L == 0) {
 			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
 			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, fs, w, h, n0,
-			                   tile, rank, nranks, recurse ? 1 : 0, geo, shade, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
+			                   tile, rank, nranks, recurse ? 1 : 0, geo, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
 		} else {
 			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created
 			hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, n_ptr,
@@ -1362,7 +1374,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 			break;
 		}
 		NodeGeo* child_geo = ctx->d_nodes_a.as<NodeGeo>() + off[L + 1];
-		unsigned int* child_occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L + 1] : nullptr;
+		unsigned int* child_occl = ctx->d_occ.as<unsigned int>() + off[L + 1];
 		int* child_count = lc + 8;                     // = level L+1's node count
 		const int child_cap = (int)cap[L + 1];
 		const Hit* raw = nullptr;                      // fused: children are made straight from the raw hits
@@ -1376,7 +1388,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		// texcoords of the children: from the queue's raw hits (trace_queue leaves them in d_hits for triangles)
 		const Hit* tc_hits = (sv.num_spheres > 0 && sv.num_tris == 0) ? nullptr : ctx->d_hits.as<Hit>();
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
-		                   lc + 1, 0, gate, child_geo, child_occl, child_count, child_cap, fc + 1, tc_hits, level_uv(L + 1));
+		                   lc + 1, 0, gate, child_geo, child_occl, child_count, child_cap, fc + 1, tc_hits, level_uv(L + 1), occl);
 		// refraction, gated after the reflection hits are known (Q9)
 		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, n_ptr, gate, q_org, q_dir,
 		                   q_parent, lc + 2);
@@ -1384,7 +1396,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		if (fuse) RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2));
 		else RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
-		                   lc + 2, 1, gate, child_geo, child_occl, child_count, child_cap, fc + 1, tc_hits, level_uv(L + 1));
+		                   lc + 2, 1, gate, child_geo, child_occl, child_count, child_cap, fc + 1, tc_hits, level_uv(L + 1), occl);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	for (int L = bounces - 1; L >= 0; --L) {
@@ -1392,7 +1404,7 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + off[L];
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + off[L - 1] : nullptr;
-		const unsigned int* occl = shadows ? ctx->d_occ.as<unsigned int>() + off[L] : nullptr;
+		const unsigned int* occl = ctx->d_occ.as<unsigned int>() + off[L];
 		hipLaunchKernelGGL(k_combine, dim3(nblocks((int)cap[L], BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, (int)cap[L], n_ptr, L,
 		                   pshade, fs, fs.packed ? fs.per_frame : w * h, (float*)nullptr, 1, occl, level_uv(L));
 		RT_HIP_CHECK(hipGetLastError());
@@ -1443,7 +1455,8 @@ int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float
 	// synchronous path.  RT_HIP_FRAME_SYNC=1 forces it (tests compare the two).
 	const char* e = getenv("RT_HIP_FRAME_SYNC");
 	const int force_sync = e ? atoi(e) : 0;
-	if (!ctx->cfg.use_photon_map && !force_sync) {
+	// (more lights than the mask word has room for beside the child flags: the synchronous driver as well)
+	if (!ctx->cfg.use_photon_map && !force_sync && (int)ctx->lights.size() <= FRAME_ASYNC_MAX_LIGHTS) {
 		FrameSet fs;
 		memset(&fs, 0, sizeof(fs));
 		fs.nframes = nframes;
@@ -1609,7 +1622,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
 			                   q_parent, nq, (const int*)nullptr, 0, gate, child_geo, (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
-			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]));
+			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 		}
 		// refraction, gated after the reflection hits are known (Q9)
@@ -1626,7 +1639,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
 			                   q_parent, nq, (const int*)nullptr, 1, gate, child_geo, (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
-			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]));
+			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
 			RT_HIP_CHECK(hipStreamSynchronize(st));
