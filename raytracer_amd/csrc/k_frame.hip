@@ -1361,8 +1361,9 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
 			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, fs, w, h, n0,
 			                   tile, rank, nranks, recurse ? 1 : 0, geo, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
-		} else {
-			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created
+		} else if (recurse) {
+			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created.  The last
+			// level needs nothing here: no rays to spawn, the light term is k_combine's, NodeShade stays unwritten.
 			hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, n_ptr,
 			                   (const unsigned int*)nullptr, (const float*)nullptr, ctx->cfg.do_shadows, 1, recurse ? 1 : 0, gate,
 			                   q_org, q_dir, q_parent, lc + 1);
