@@ -25,14 +25,18 @@ struct __attribute__((aligned(16))) HitInfo {
 	float pad;
 };
 
-struct __attribute__((aligned(16))) NodeGeo {   // 48 B
+// 32 bytes: what the shadow rays (read once per light) and the combine need.  The incident direction,
+// which only the kernels that spawn reflection / refraction rays read, lives in an array of its own
+// (3 floats per node), so the per-light streams carry a third less.
+struct __attribute__((aligned(16))) NodeGeo {
 	float V[3];
-	int parent;    // level 0: pixel index; deeper: index of the parent node in the previous level
+	int parent;    // level 0: frame * pixels + pixel (or -1); deeper: index of the parent node in the previous level | branch << 31
 	float N[3];
-	int material;  // -1: inactive
-	float I[3];
-	int branch;    // 0 reflection child, 1 refraction child
+	int material;  // -1: inactive, -2: no node (padding / another rank's texel)
 };
+static_assert(sizeof(NodeGeo) == 32, "node record");
+__device__ __forceinline__ int node_parent(const NodeGeo& g) { return g.parent & 0x7fffffff; }
+__device__ __forceinline__ int node_branch(const NodeGeo& g) { return (int)((unsigned int)g.parent >> 31); }  // 0 reflection child, 1 refraction child
 // Sync-free frame driver: a node's shadow mask word also says which children it has (set by
 // k_make_children), so that NodeShade needs no zero-initialisation: k_combine reads the colour a child
 // returned only where that child exists.  Lights therefore use bits [0, 30).
@@ -387,7 +391,8 @@ __device__ __forceinline__ bool tile_is_mine(int pixel, int w, int tile, int ran
 __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__ pos_rgb,
                                                       const float* __restrict__ nrm_rgba, int w, int h, int n0, int tile,
                                                       int rank, int nranks, int num_materials,
-                                                      NodeGeo* __restrict__ geo, int* __restrict__ active_count,
+                                                      NodeGeo* __restrict__ geo, float* __restrict__ inc,
+                                                      int* __restrict__ active_count,
                                                       const float* __restrict__ uv_plane, float* __restrict__ node_uv)
 {
 	int j = blockIdx.x * CBLOCK + threadIdx.x;
@@ -409,8 +414,8 @@ __global__ __launch_bounds__(CBLOCK) void k_init_nodes(const float* __restrict__
 			N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
 		}
 		st3(g.V, P); st3(g.N, N);
-		st3(g.I, mat >= 0 ? normalized3(P) : mk3(0, 0, 0));
-		g.parent = i; g.material = mat; g.branch = 0;
+		st3(inc + 3 * (size_t)j, mat >= 0 ? normalized3(P) : mk3(0, 0, 0));
+		g.parent = i; g.material = mat;
 		geo[j] = g;
 		active = mat >= 0;
 		if (node_uv) {  // textured scenes only
@@ -452,7 +457,7 @@ __device__ __forceinline__ int level0_pixel(const FrameSet& fs, int jj, int w, i
 
 __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs, int w, int h, int n0, int tile,
                                                       int rank, int nranks, int recurse, NodeGeo* __restrict__ geo,
-                                                      int* __restrict__ gate,
+                                                      float* __restrict__ inc, int* __restrict__ gate,
                                                       unsigned int* __restrict__ occl, float* __restrict__ q_org,
                                                       float* __restrict__ q_dir, int* __restrict__ q_parent,
                                                       int* __restrict__ q_count, int* __restrict__ active_count,
@@ -483,10 +488,11 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
 		active = mat >= 0;
 		const f3 I = active ? normalized3(P) : mk3(0, 0, 0);
 		NodeGeo g;
-		st3(g.V, P); st3(g.N, N); st3(g.I, I);
+		st3(g.V, P); st3(g.N, N);
+		st3(inc + 3 * (size_t)j, I);
 		// where k_combine writes this node's pixel: frame f's image, or (packed) the rank's chunk of frame f
 		g.parent = i < 0 ? -1 : (fs.packed ? f * fs.per_frame + slot : f * (w * h) + i);
-		g.material = mat; g.branch = 0;
+		g.material = mat;
 		geo[j] = g;
 		gate[j] = active ? mat : -1;
 		occl[j] = 0u;  // shadow mask + child flags; NodeShade stays unwritten until a child returns a colour
@@ -605,6 +611,7 @@ __device__ __forceinline__ float light_factor(const SceneView& sv, f3 V, f3 N, u
 // defer_light: F is left to k_combine (the shadow rays of this level may still be in flight on the
 // side stream); only the gate and the reflection rays are produced here.
 __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, const NodeGeo* __restrict__ geo,
+                                                               const float* __restrict__ inc,
                                                                NodeShade* __restrict__ shade, int n,
                                                                const int* __restrict__ n_ptr,
                                                                const unsigned int* __restrict__ occl,
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, co
 		st3(s.refc, mk3(0, 0, 0)); st3(s.refrc, mk3(0, 0, 0));
 		if (g.material >= 0) {
 			V = ld3(g.V);
-			f3 N = ld3(g.N), I = ld3(g.I);
+			f3 N = ld3(g.N);
 			const MaterialRec m = sv.materials[g.material];
 			if (photon_rgb) {
 				st3(s.F, ld3(photon_rgb + 3 * (size_t)i));  // shadow == 1
@@ -636,6 +643,7 @@ __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, co
 			}
 			gate[i] = g.material;
 			if (recurse && m.reflectivity > 0.0f) {
+				const f3 I = ld3(inc + 3 * (size_t)i);
 				R = I - N * (2.0f * dot3(I, N));
 				emit = true;
 			}
@@ -655,7 +663,8 @@ __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, co
 }
 
 // Refraction spawn: gated by the (possibly overwritten, quirk Q9) material.
-__global__ __launch_bounds__(CBLOCK) void k_spawn_refract(SceneView sv, const NodeGeo* __restrict__ geo, int n,
+__global__ __launch_bounds__(CBLOCK) void k_spawn_refract(SceneView sv, const NodeGeo* __restrict__ geo,
+                                                         const float* __restrict__ inc, int n,
                                                          const int* __restrict__ n_ptr, const int* __restrict__ gate, float* __restrict__ q_org,
                                                          float* __restrict__ q_dir, int* __restrict__ q_parent,
                                                          int* __restrict__ q_count)
@@ -671,7 +680,7 @@ __global__ __launch_bounds__(CBLOCK) void k_spawn_refract(SceneView sv, const No
 			if (m.alpha > 0.1f) {
 				const NodeGeo g = geo[i];
 				V = ld3(g.V);
-				f3 N = ld3(g.N), I = ld3(g.I);
+				f3 N = ld3(g.N), I = ld3(inc + 3 * (size_t)i);
 				float IoR = m.ior;
 				float idn = dot3(I, N);
 				T = div3(I - N * idn, IoR);
@@ -720,6 +729,7 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
                                                          const int* __restrict__ q_parent, int nq,
                                                          const int* __restrict__ n_ptr, int branch,
                                                          int* __restrict__ gate, NodeGeo* __restrict__ child_geo,
+                                                         float* __restrict__ child_inc,
                                                          unsigned int* __restrict__ child_occl,
                                                          int* __restrict__ child_count, int child_capacity,
                                                          int* __restrict__ overflow, const Hit* __restrict__ tc_hits,
@@ -745,13 +755,13 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
 	if (hit && slot >= child_capacity) { *overflow = 1; hit = false; }  // the host re-renders with exact sizes
 	if (hit) {
 		NodeGeo g;
-		for (int k = 0; k < 3; ++k) { g.V[k] = h.pos[k]; g.N[k] = h.nrm[k]; g.I[k] = q_dir[3 * (size_t)i + k]; }
-		g.parent = q_parent[i];
+		for (int k = 0; k < 3; ++k) { g.V[k] = h.pos[k]; g.N[k] = h.nrm[k]; child_inc[3 * (size_t)slot + k] = q_dir[3 * (size_t)i + k]; }
+		const int parent = q_parent[i];
+		g.parent = parent | (int)((unsigned int)branch << 31);
 		g.material = h.material;
-		g.branch = branch;
 		child_geo[slot] = g;
 		if (child_occl) child_occl[slot] = 0u;
-		if (parent_flags) atomicOr(&parent_flags[g.parent], branch == 0 ? CHILD_REFL_BIT : CHILD_REFR_BIT);
+		if (parent_flags) atomicOr(&parent_flags[parent], branch == 0 ? CHILD_REFL_BIT : CHILD_REFR_BIT);
 		if (child_uv) { child_uv[2 * (size_t)slot] = tc[0]; child_uv[2 * (size_t)slot + 1] = tc[1]; }
 	}
 }
@@ -799,7 +809,7 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 		col = mk3(F.x * mix.x, F.y * mix.y, F.z * mix.z);
 	}
 	if (level > 0) {
-		float* dst = g.branch == 0 ? parent_shade[g.parent].refc : parent_shade[g.parent].refrc;
+		float* dst = node_branch(g) == 0 ? parent_shade[node_parent(g)].refc : parent_shade[node_parent(g)].refrc;
 		st3(dst, col);
 	} else {
 		const int f = g.parent / frame_pixels, pixel = g.parent - f * frame_pixels;  // level 0: parent = frame * pixels + pixel
@@ -1300,6 +1310,8 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	RT_CHECK(ctx->d_nodes_a.reserve((size_t)off[bounces] * sizeof(NodeGeo)));
 	RT_CHECK(ctx->d_nodes_b.reserve((size_t)off[bounces] * sizeof(NodeShade)));
 	RT_CHECK(ctx->d_gate.reserve((size_t)off[bounces] * sizeof(int)));
+	RT_CHECK(ctx->d_node_inc.reserve((size_t)off[bounces] * 12));  // incident directions, 3 floats per node
+	float* const inc_base = ctx->d_node_inc.as<float>();
 	if (sv.tex) RT_CHECK(ctx->d_node_uv.reserve((size_t)off[bounces] * 8));  // textured scenes: a texcoord per node
 	float* const uv_base = sv.tex ? ctx->d_node_uv.as<float>() : nullptr;
 	auto level_uv = [&](int L) -> float* { return uv_base ? uv_base + 2 * (size_t)off[L] : nullptr; };
@@ -1360,11 +1372,12 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		if (L == 0) {
 			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
 			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, fs, w, h, n0,
-			                   tile, rank, nranks, recurse ? 1 : 0, geo, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
+			                   tile, rank, nranks, recurse ? 1 : 0, geo, inc_base, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
 		} else if (recurse) {
 			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created.  The last
 			// level needs nothing here: no rays to spawn, the light term is k_combine's, NodeShade stays unwritten.
-			hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n, n_ptr,
+			hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo,
+			                   (const float*)(inc_base + 3 * (size_t)off[L]), shade, n, n_ptr,
 			                   (const unsigned int*)nullptr, (const float*)nullptr, ctx->cfg.do_shadows, 1, recurse ? 1 : 0, gate,
 			                   q_org, q_dir, q_parent, lc + 1);
 		}
@@ -1389,15 +1402,17 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		// texcoords of the children: from the queue's raw hits (trace_queue leaves them in d_hits for triangles)
 		const Hit* tc_hits = (sv.num_spheres > 0 && sv.num_tris == 0) ? nullptr : ctx->d_hits.as<Hit>();
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
-		                   lc + 1, 0, gate, child_geo, child_occl, child_count, child_cap, fc + 1, tc_hits, level_uv(L + 1), occl);
+		                   lc + 1, 0, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
+		                   level_uv(L + 1), occl);
 		// refraction, gated after the reflection hits are known (Q9)
-		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, n_ptr, gate, q_org, q_dir,
-		                   q_parent, lc + 2);
+		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo,
+		                   (const float*)(inc_base + 3 * (size_t)off[L]), n, n_ptr, gate, q_org, q_dir, q_parent, lc + 2);
 		RT_HIP_CHECK(hipGetLastError());
 		if (fuse) RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2));
 		else RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
-		                   lc + 2, 1, gate, child_geo, child_occl, child_count, child_cap, fc + 1, tc_hits, level_uv(L + 1), occl);
+		                   lc + 2, 1, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
+		                   level_uv(L + 1), occl);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	for (int L = bounces - 1; L >= 0; --L) {
@@ -1526,11 +1541,13 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		RT_CHECK(ctx->d_nodes_a.reserve(nodes * sizeof(NodeGeo)));
 		RT_CHECK(ctx->d_nodes_b.reserve(nodes * sizeof(NodeShade)));
 		RT_CHECK(ctx->d_gate.reserve(nodes * sizeof(int)));
+		RT_CHECK(ctx->d_node_inc.reserve(nodes * 12));
 		if (sv.tex) RT_CHECK(ctx->d_node_uv.reserve(nodes * 8));  // textured scenes: a texcoord per node
 		return RT_HIP_OK;
 	};
 	// (re)fetched at every use: reserve() may move the buffer
 	auto level_uv = [&](size_t node_off) -> float* { return sv.tex ? ctx->d_node_uv.as<float>() + 2 * node_off : nullptr; };
+	auto level_inc = [&](size_t node_off) -> float* { return ctx->d_node_inc.as<float>() + 3 * node_off; };
 	// worst case for the next level is 2 children per node; reserve level 0 + level 1 bound up front
 	RT_CHECK(ensure_nodes((size_t)npix * (bounces > 1 ? 3 : 1)));
 	RT_CHECK(ctx->d_qcount.reserve(64));
@@ -1540,7 +1557,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
 	RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 64, st));
 	hipLaunchKernelGGL(k_init_nodes, dim3(nblocks(npix, CBLOCK)), dim3(CBLOCK), 0, st, d_pos_rgb, d_nrm_rgba, w, h, npix, tile, rank,
-	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), qcount + 8, d_uv, level_uv(0));
+	                   nranks, sv.num_materials, ctx->d_nodes_a.as<NodeGeo>(), level_inc(0), qcount + 8, d_uv, level_uv(0));
 	RT_HIP_CHECK(hipGetLastError());
 	int active0 = 0;
 	RT_HIP_CHECK(hipMemcpyAsync(&active0, qcount + 8, 4, hipMemcpyDeviceToHost, st));
@@ -1601,8 +1618,8 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		HitInfo* d_hi = ctx->d_records.as<HitInfo>();
 
 		RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 16, st));
-		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, shade, n,
-		                   (const int*)nullptr, occl, photon_rgb, ctx->cfg.do_shadows, 0, recurse ? 1 : 0, gate, q_org, q_dir, q_parent, qcount);
+		hipLaunchKernelGGL(k_light_spawn_reflect, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo,
+		                   (const float*)level_inc(geo_off[L]), shade, n, (const int*)nullptr, occl, photon_rgb, ctx->cfg.do_shadows, 0, recurse ? 1 : 0, gate, q_org, q_dir, q_parent, qcount);
 		RT_HIP_CHECK(hipGetLastError());
 		if (!recurse) break;
 
@@ -1622,14 +1639,14 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			rays += nq;
 			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
-			                   q_parent, nq, (const int*)nullptr, 0, gate, child_geo, (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
+			                   q_parent, nq, (const int*)nullptr, 0, gate, child_geo, level_inc(geo_off[L + 1]), (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
 			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 		}
 		// refraction, gated after the reflection hits are known (Q9)
 		RT_HIP_CHECK(hipMemsetAsync(qcount, 0, 4, st));
-		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo, n, (const int*)nullptr, gate,
-		                   q_org, q_dir, q_parent, qcount);
+		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo,
+		                   (const float*)level_inc(geo_off[L]), n, (const int*)nullptr, gate, q_org, q_dir, q_parent, qcount);
 		RT_HIP_CHECK(hipGetLastError());
 		RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
 		RT_HIP_CHECK(hipStreamSynchronize(st));
@@ -1639,7 +1656,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			rays += nq;
 			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
-			                   q_parent, nq, (const int*)nullptr, 1, gate, child_geo, (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
+			                   q_parent, nq, (const int*)nullptr, 1, gate, child_geo, level_inc(geo_off[L + 1]), (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
 			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
