@@ -68,7 +68,8 @@ class TileExchange:
         self.cur = b ^ 1
 
     def finish(self, d_frame_rgba):
-        """Wait for the all-to-all begun last and assemble frame `rank` in d_frame_rgba (no-op if none is in flight)."""
+        """Wait for the all-to-all begun last and queue the kernel that assembles frame `rank` in d_frame_rgba on the
+        context's stream (no-op if none is in flight).  Readers on another stream call ctx.sync() first."""
         if self.pending is None:
             return
         work, b, host_recv = self.pending
@@ -77,7 +78,10 @@ class TileExchange:
         if host_recv is not None:
             self.recv[b].copy_(host_recv)
         torch.cuda.current_stream().synchronize()                 # chunks landed before the context's stream reads them
-        self.ctx.unpack_chunks_device(self.recv[b], self.chunk, self.w, self.h, self.tile, self.world, d_frame_rgba)
+        # un-fenced entry: the unpack kernel is queued on the context's stream and the host moves on; the next render
+        # queues behind it, and recv[b] is not written again before a later render has drained that stream
+        type(self.ctx).unpack_chunks_device.__wrapped__(self.ctx, self.recv[b], self.chunk, self.w, self.h, self.tile, self.world,
+                                                        d_frame_rgba)
 
     def exchange(self, d_frame_rgba):
         """All-to-all of the packed chunks, then assemble frame `rank` in d_frame_rgba."""
