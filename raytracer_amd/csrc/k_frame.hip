@@ -608,8 +608,8 @@ __device__ __forceinline__ float light_factor(const SceneView& sv, f3 V, f3 N, u
 }
 
 // Per node: lambert / shadow -> F, and the reflection ray if this level may recurse.
-// defer_light: F is left to k_combine (the shadow rays of this level may still be in flight on the
-// side stream); only the gate and the reflection rays are produced here.
+// defer_light (sync-free driver): F is left to k_combine, which runs after all shadow launches of the
+// level; only the gate and the reflection rays are produced here and NodeShade is not written.
 __global__ __launch_bounds__(CBLOCK) void k_light_spawn_reflect(SceneView sv, const NodeGeo* __restrict__ geo,
                                                                const float* __restrict__ inc,
                                                                NodeShade* __restrict__ shade, int n,

@@ -173,7 +173,7 @@ unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls)
 	if (!ctx->cfg.census) return nullptr;
 	if (!ctx->d_census.p) {
 		if (ctx->d_census.reserve(64) != RT_HIP_OK) return nullptr;
-		if (hipMemset(ctx->d_census.p, 0, 64) != hipSuccess) return nullptr;  // synchronous: two streams add to it
+		if (hipMemset(ctx->d_census.p, 0, 64) != hipSuccess) return nullptr;  // synchronous: done before any kernel adds to it
 	}
 	return ctx->d_census.as<unsigned long long>() + (cls ? 3 : 0);
 }
