@@ -224,6 +224,11 @@ __global__ __launch_bounds__(BLOCK) void k_material_digit(SceneView sv, const Hi
 	digit[i] = (key >> shift) & 255u;
 }
 
+__global__ __launch_bounds__(128) void k_zero_ints(int* __restrict__ p, int n)
+{
+	for (int k = threadIdx.x; k < n; k += 128) p[k] = 0;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_iota(uint32_t* p, int n)
 {
 	int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -1322,8 +1327,8 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	// frame counters: [0] active level-0 nodes, [1] overflow flag,
 	// [8 + 8L + 0] nodes of level L, [.. + 1] reflection rays of level L, [.. + 2] refraction rays
 	const int nfc = 8 + 8 * (bounces + 1);
-	RT_CHECK(ctx->d_qcount.reserve((size_t)nfc * 4));
-	int* fc = ctx->d_qcount.as<int>();
+	RT_CHECK(ctx->d_fcount.reserve((size_t)nfc * 4));  // this driver's own: nothing else writes to it
+	int* fc = ctx->d_fcount.as<int>();
 	float* q_org = ctx->d_rays_q.as<float>();
 	float* q_dir = q_org + (size_t)maxcap * 3;
 	int* q_parent = ctx->d_ray_parent.as<int>();
@@ -1359,7 +1364,10 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		return RT_HIP_OK;
 	};
 	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
-	RT_HIP_CHECK(hipMemsetAsync(fc, 0, (size_t)nfc * 4, st));
+	// The counters are zeroed at the END of a frame, behind its read-back, for the frame that follows: the
+	// first thing a frame queues is then its first kernel, not a fill and the host time after it.
+	if (ctx->fcount_clean != fc || ctx->fcount_clean_n < nfc) RT_HIP_CHECK(hipMemsetAsync(fc, 0, (size_t)nfc * 4, st));
+	ctx->fcount_clean = nullptr;
 	for (int L = 0; L < bounces; ++L) {
 		const int n = (int)cap[L];
 		int* lc = fc + 8 + 8 * L;                      // this level's counters
@@ -1428,6 +1436,9 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	int* h_fc = (int*)ctx->h_small;  // 4 KiB pinned; nfc <= 80 ints
 	RT_HIP_CHECK(hipMemcpyAsync(h_fc, fc, (size_t)nfc * 4, hipMemcpyDeviceToHost, st));
 	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+	hipLaunchKernelGGL(k_zero_ints, dim3(1), dim3(128), 0, st, fc, nfc);  // behind the event: for the next frame
+	RT_HIP_CHECK(hipGetLastError());
+	ctx->fcount_clean = fc; ctx->fcount_clean_n = nfc;
 	RT_HIP_CHECK(hipEventSynchronize(ctx->ev1));
 	if (h_fc[1]) {
 		*overflowed = true;
