@@ -277,6 +277,31 @@ __global__ __launch_bounds__(BLOCK) void k_emit_records(SceneView sv, const floa
 	r[12] = tc[0]; r[13] = tc[1]; r[14] = 0.0f; r[15] = 0.0f;
 }
 
+// The same from the ray's side: ray i, if it hit, writes its record to slot dest[i] (its rank in the
+// one-pass grouping; misses rank last and write nothing).  Needs neither the inverse permutation nor
+// the hit count, so it is queued before the host reads the group sizes.
+__global__ __launch_bounds__(BLOCK) void k_emit_records_scatter(SceneView sv, const float* __restrict__ org,
+                                                                const float* __restrict__ dir, const Hit* __restrict__ hits,
+                                                                const uint32_t* __restrict__ dest, int n,
+                                                                rt_ray* __restrict__ records)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const Hit h = hits[i];
+	if (h.prim == RT_MISS) return;
+	HitInfo hi;
+	float tc[2];
+	resolve_tri(sv, h, hi, tc);
+	float* r = (float*)(records + dest[i]);
+	for (int k = 0; k < 3; ++k) {
+		r[k] = org[3 * (size_t)i + k];
+		r[3 + k] = dir[3 * (size_t)i + k];
+		r[6 + k] = hi.pos[k];
+		r[9 + k] = hi.nrm[k];
+	}
+	r[12] = tc[0]; r[13] = tc[1]; r[14] = 0.0f; r[15] = 0.0f;
+}
+
 // ---- G-buffer select -------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_select_digit(const float* __restrict__ nrm_rgba, int n, int interlace,
                                                         int phase, uint32_t* __restrict__ digit)
@@ -1143,9 +1168,14 @@ int rt_group_by_material(rt_hip_ctx* ctx, const float* d_org, const float* d_dir
 	// pass 1: low byte (misses carry 0xFF / 0xFFFF and sort last)
 	hipLaunchKernelGGL(k_material_digit, dim3(g), dim3(BLOCK), 0, st, sv, d_hits, n, 0, digit);
 	RT_CHECK(rt_multisplit256(ctx, digit, n, dest, totals));
-	hipLaunchKernelGGL(k_iota, dim3(g), dim3(BLOCK), 0, st, perm_b, n);
-	hipLaunchKernelGGL(k_apply_dest, dim3(g), dim3(BLOCK), 0, st, perm_b, dest, n, perm_a);
 	uint32_t* perm = perm_a;
+	if (two_pass) {
+		hipLaunchKernelGGL(k_iota, dim3(g), dim3(BLOCK), 0, st, perm_b, n);
+		hipLaunchKernelGGL(k_apply_dest, dim3(g), dim3(BLOCK), 0, st, perm_b, dest, n, perm_a);
+	} else if (d_records) {
+		// one pass: dest[i] is ray i's final slot; the records go out before the host has seen any count
+		hipLaunchKernelGGL(k_emit_records_scatter, dim3(g), dim3(BLOCK), 0, st, sv, d_org, d_dir, d_hits, dest, n, d_records);
+	}
 	std::vector<uint32_t> h_lo(256), h_hi(256);
 	RT_HIP_CHECK(hipMemcpyAsync(h_lo.data(), totals, 256 * 4, hipMemcpyDeviceToHost, st));
 	if (two_pass) {
@@ -1161,7 +1191,7 @@ int rt_group_by_material(rt_hip_ctx* ctx, const float* d_org, const float* d_dir
 	// With two passes the high-byte bucket 255 holds only misses as long as nmat < 0xFF00.
 	int nres = n - misses;
 	*out_results = nres;
-	if (nres > 0) {
+	if (nres > 0 && two_pass) {
 		hipLaunchKernelGGL(k_emit_records, dim3(nblocks(nres, BLOCK)), dim3(BLOCK), 0, st, sv, d_org, d_dir, d_hits, perm,
 		                   nres, d_records);
 		RT_HIP_CHECK(hipGetLastError());
