@@ -237,7 +237,12 @@ int rt_hip_set_frame_texcoords_device(rt_hip_ctx* ctx, const float* const* d_uv,
 /* Gen-1 shade() (rt_raytracer.cpp:75-160) evaluated at every G-buffer texel with alpha > 0
  * (material id = alpha - 1), secondary rays (shadow, reflection, refraction) traced on the GPU;
  * RGBA8 written as renderScene does (rt_raytracer.cpp:175-185).  Frame semantics: DESIGN.md.
- * Host entry: uploads with hipMemcpyAsync, downloads the image. */
+ * Host entry: uploads with hipMemcpyAsync, downloads the image.
+ * Limits (RT_HIP_ERR_LIMIT beyond them): 32 lights, 8 bounces, 2^26 texels per frame.  Two drivers
+ * render the same image: the default one sizes every level of the ray tree by its bound and never
+ * returns to the host inside a frame; frames with a photon map, with more than 30 lights, or too
+ * large to be sized by bounds are rendered level by level with counts read back (so is any frame
+ * when RT_HIP_FRAME_SYNC=1). */
 int rt_hip_render_frame(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float* gbuf_nrm_rgba, int width,
                         int height, uint8_t* rgba_out);
 int rt_hip_render_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba,
