@@ -196,18 +196,43 @@ struct GatherConst {
 	float alpha, beta, e, gauss_denom, two_pi;
 };
 
-// Visit every photon whose grid cell intersects the cube of half-width rho around P (a superset of
-// the sphere of radius rho).  Cells along x are contiguous in the sorted array: one span per (y,z).
+// The x-cells of grid row (y, z) that can hold a photon within rho of P: the row's distance from P in the
+// yz-plane bounds the chord of the sphere along x.  false: the whole row is out of reach.
+__device__ __forceinline__ bool row_chord(const GridDesc& gd, f3 P, float rho, int y, int z, int& x0, int& x1)
+{
+	const float ylo = gd.mn[1] + (float)y * gd.cell, zlo = gd.mn[2] + (float)z * gd.cell;
+	// distance from P to the row's [lo, lo + cell] interval per axis (0 inside); the border rows of the grid
+	// also hold what cell_coord clamped into them, so they count as reaching to infinity
+	float dy = fmaxf(fmaxf(ylo - P.y, P.y - (ylo + gd.cell)), 0.0f);
+	float dz = fmaxf(fmaxf(zlo - P.z, P.z - (zlo + gd.cell)), 0.0f);
+	if ((y == 0 && P.y < ylo) || (y == gd.dim[1] - 1 && P.y > ylo + gd.cell)) dy = 0.0f;
+	if ((z == 0 && P.z < zlo) || (z == gd.dim[2] - 1 && P.z > zlo + gd.cell)) dz = 0.0f;
+	// never over-estimate a gap: the row edges computed here and cell_coord's floor() may disagree by a few ulps of
+	// the grid's extent, far below a ten-thousandth of a cell
+	const float slack = gd.cell * 1e-4f;
+	dy = fmaxf(dy * 0.9999f - slack, 0.0f); dz = fmaxf(dz * 0.9999f - slack, 0.0f);
+	const float h2 = rho * rho - (dy * dy + dz * dz);
+	if (h2 < 0.0f) return false;
+	const float half = rt_sqrtf(h2) * 1.0001f + slack;
+	x0 = cell_coord(P.x - half, gd.mn[0], gd.inv_cell, gd.dim[0]);
+	x1 = cell_coord(P.x + half, gd.mn[0], gd.inv_cell, gd.dim[0]);
+	return true;
+}
+
+// Visit every photon whose grid cell can hold a photon within rho of P: the rows (y, z) of the cube of
+// half-width rho, each cut to the sphere's chord.  Cells along x are contiguous in the sorted array: one
+// span per row.
 template <typename F>
 __device__ __forceinline__ void for_each_neighbour(const GridDesc& gd, const uint32_t* __restrict__ cell_start,
                                                    const float4* __restrict__ pos, f3 P, float rho, F f)
 {
 	rho = rho * 1.0001f + 1e-30f;  // the cell of a photon at distance <= rho must not fall outside by rounding
-	int x0 = cell_coord(P.x - rho, gd.mn[0], gd.inv_cell, gd.dim[0]), x1 = cell_coord(P.x + rho, gd.mn[0], gd.inv_cell, gd.dim[0]);
 	int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
 	int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
 	for (int z = z0; z <= z1; ++z)
 		for (int y = y0; y <= y1; ++y) {
+			int x0, x1;
+			if (!row_chord(gd, P, rho, y, z, x0, x1)) continue;
 			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
 			uint32_t s0 = cell_start[row + x0], s1 = cell_start[row + x1 + 1];
 			// eight photons in flight per lane: the loads are independent of the loop body, and a
@@ -235,12 +260,13 @@ __device__ __forceinline__ void for_each_neighbour(const GridDesc& gd, const uin
 __device__ __forceinline__ uint32_t cube_population(const GridDesc& gd, const uint32_t* __restrict__ cell_start, f3 P, float rho)
 {
 	rho = rho * 1.0001f + 1e-30f;
-	int x0 = cell_coord(P.x - rho, gd.mn[0], gd.inv_cell, gd.dim[0]), x1 = cell_coord(P.x + rho, gd.mn[0], gd.inv_cell, gd.dim[0]);
 	int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
 	int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
 	uint32_t total = 0;
 	for (int z = z0; z <= z1; ++z)
 		for (int y = y0; y <= y1; ++y) {
+			int x0, x1;
+			if (!row_chord(gd, P, rho, y, z, x0, x1)) continue;
 			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
 			total += cell_start[row + x1 + 1] - cell_start[row + x0];
 		}
@@ -254,12 +280,13 @@ __device__ __forceinline__ void for_each_neighbour_wave(const GridDesc& gd, cons
                                                         const float4* __restrict__ pos, f3 P, float rho, F f)
 {
 	rho = rho * 1.0001f + 1e-30f;
-	int x0 = cell_coord(P.x - rho, gd.mn[0], gd.inv_cell, gd.dim[0]), x1 = cell_coord(P.x + rho, gd.mn[0], gd.inv_cell, gd.dim[0]);
 	int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
 	int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
 	const uint32_t lane = (uint32_t)lane_id();
 	for (int z = z0; z <= z1; ++z)
 		for (int y = y0; y <= y1; ++y) {
+			int x0, x1;
+			if (!row_chord(gd, P, rho, y, z, x0, x1)) continue;
 			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
 			const uint32_t s0 = cell_start[row + x0], s1 = cell_start[row + x1 + 1];
 			uint32_t s = s0;
