@@ -62,7 +62,7 @@ def parse_args():
                     choices=["atrium-262k-1080p", "atrium-1m-1080p", "atrium-1m-4k", "cornell-1080p", "atrium-8k-small"])
     ap.add_argument("--shadow-mode", default="corrected", choices=["corrected", "literal"],
                     help="corrected: a hit shadows only before the light (shadow_t_max=1); literal: the reference's any-hit")
-    ap.add_argument("--accel", default="ploc", choices=["lbvh", "ploc"], help="BVH builder (both on the GPU)")
+    ap.add_argument("--accel", default="ploc", choices=["lbvh", "ploc", "sah"], help="BVH builder (lbvh, ploc: on the GPU; sah: one host thread, static scenes)")
     ap.add_argument("--photons", type=int, default=0,
                     help="C5: photons per light (0 = off).  The sharded photon pass (emit -> RCCL all-gather -> grid) runs once, "
                          "untimed by `value` and reported as config.photon_pass_ms; frames then shade with radiance_estimate "
@@ -117,9 +117,10 @@ def main():
 
     wl = WORKLOADS[args.workload]
     W, H = wl["w"], wl["h"]
+    ACCEL = {"lbvh": rt.ACCEL_LBVH, "ploc": rt.ACCEL_PLOC, "sah": rt.ACCEL_SAH}
     scene = scenes.cornell() if wl["tris"] == 0 else scenes.atrium(wl["tris"])
     shadow_t_max = 1.0 if args.shadow_mode == "corrected" else 0.0
-    g = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_PLOC if args.accel == "ploc" else rt.ACCEL_LBVH, device=dev_index, profile=1, bounces=2, do_shadows=1,
+    g = rt.RtHip(scene, semantics="array", accel=ACCEL[args.accel], device=dev_index, profile=1, bounces=2, do_shadows=1,
                  shadow_t_max=shadow_t_max, use_photon_map=1 if args.photons > 0 else 0, photon_estimate=100,
                  photon_radius=1.0, seed=42)
     build_stats = g.stats()
@@ -197,7 +198,7 @@ def main():
     inflight = max(1, args.inflight) if world == 1 and args.photons == 0 else 1
     extra = []
     for _ in range(inflight - 1):
-        ge = rt.RtHip(scene, semantics="array", accel=rt.ACCEL_PLOC if args.accel == "ploc" else rt.ACCEL_LBVH, device=dev_index,
+        ge = rt.RtHip(scene, semantics="array", accel=ACCEL[args.accel], device=dev_index,
                       profile=0, bounces=2, do_shadows=1, shadow_t_max=shadow_t_max, seed=42)
         extra.append((ge, [torch.zeros(npix * 4, dtype=torch.uint8, device=dev)]))
 

@@ -83,8 +83,11 @@ typedef struct rt_hit {
 
 enum rt_hip_geometry { RT_HIP_TRIANGLES = 0, RT_HIP_SPHERES = 1 };
 /* LBVH: Morton-split hierarchy (fastest build).  PLOC: agglomerative build over the same Morton
- * order, topology by surface area (fewer node visits per ray, a few ms more to build). */
-enum rt_hip_accel { RT_HIP_ACCEL_AUTO = 0, RT_HIP_ACCEL_BRUTE = 1, RT_HIP_ACCEL_LBVH = 2, RT_HIP_ACCEL_PLOC = 3 };
+ * order, topology by surface area (fewer node visits per ray, a few ms more to build).  SAH: top-down
+ * binned surface-area heuristic on ONE HOST THREAD (hundreds of ms; for scenes that do not change),
+ * same node format and traversal. */
+enum rt_hip_accel { RT_HIP_ACCEL_AUTO = 0, RT_HIP_ACCEL_BRUTE = 1, RT_HIP_ACCEL_LBVH = 2, RT_HIP_ACCEL_PLOC = 3,
+                    RT_HIP_ACCEL_SAH = 4 };
 
 /* Constants the reference hard-codes (file:line beside each). */
 typedef struct rt_hip_config {

@@ -32,7 +32,7 @@ assert RAY_DTYPE.itemsize == 64 and MATERIAL_DTYPE.itemsize == 48 and LIGHT_DTYP
 
 MISS = 0xFFFFFFFF
 TRIANGLES, SPHERES = 0, 1
-ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH, ACCEL_PLOC = 0, 1, 2, 3
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH, ACCEL_PLOC, ACCEL_SAH = 0, 1, 2, 3, 4
 
 
 class Config(C.Structure):

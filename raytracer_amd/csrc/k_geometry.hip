@@ -256,6 +256,7 @@ int rt_build_geometry(rt_hip_ctx* ctx)
 	for (int k = 0; k < 6; ++k) ctx->bounds[k] = ord2f(ob[k]);
 
 	bool want_bvh = ctx->cfg.accel == RT_HIP_ACCEL_LBVH || ctx->cfg.accel == RT_HIP_ACCEL_PLOC ||
+	                ctx->cfg.accel == RT_HIP_ACCEL_SAH ||
 	                (ctx->cfg.accel == RT_HIP_ACCEL_AUTO && nt >= 512);
 	if (want_bvh && nt >= 2) RT_CHECK(rt_build_lbvh(ctx));
 	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));

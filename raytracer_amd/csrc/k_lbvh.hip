@@ -468,6 +468,154 @@ static int build_ploc(rt_hip_ctx* ctx, int n, float pad, const uint32_t* order, 
 	return RT_HIP_OK;
 }
 
+// ---- binned SAH on the host (RT_HIP_ACCEL_SAH) ------------------------------------------------------
+// Top-down surface-area-heuristic build for scenes that stay put: the triangle boxes come back from the
+// device, one host thread splits [lo, hi) at the cheapest of 3 x (SAH_BINS - 1) centroid planes (every
+// candidate of a range of <= SAH_SWEEP, sorted per axis) down to single triangles, and the topology goes
+// back in the arrays the device builders fill, so node emission, quantisation and traversal are shared.
+// Node ids are handed out in pre-order: root 0, parents below their children, a left subtree contiguous.
+namespace {
+
+constexpr int SAH_BINS = 32;
+constexpr int SAH_SWEEP = 16;
+
+struct HBox {
+	float lo[3], hi[3];
+	void clear() { for (int k = 0; k < 3; ++k) { lo[k] = __builtin_inff(); hi[k] = -__builtin_inff(); } }
+	void grow(const float* mn, const float* mx) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], mn[k]); hi[k] = std::max(hi[k], mx[k]); } }
+	void grow(const HBox& b) { grow(b.lo, b.hi); }
+	float half_area() const
+	{
+		float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+		return dx * dy + (dy * dz + dz * dx);
+	}
+};
+
+// Best split of idx[lo, hi) by binned SAH; returns the position of the first element of the right side.
+int sah_split(const std::vector<float4>& box, std::vector<uint32_t>& idx, int lo, int hi, std::vector<HBox>& scratch)
+{
+	const int count = hi - lo;
+	auto centre = [&](uint32_t p, int k) {
+		const float* mn = &box[2 * (size_t)p].x; const float* mx = &box[2 * (size_t)p + 1].x;
+		return 0.5f * (mn[k] + mx[k]);
+	};
+	float cmin[3], cmax[3];
+	for (int k = 0; k < 3; ++k) { cmin[k] = __builtin_inff(); cmax[k] = -__builtin_inff(); }
+	for (int i = lo; i < hi; ++i)
+		for (int k = 0; k < 3; ++k) { float c = centre(idx[i], k); cmin[k] = std::min(cmin[k], c); cmax[k] = std::max(cmax[k], c); }
+	float best = __builtin_inff();
+	int best_axis = -1, best_pos = 0;
+	if (count <= SAH_SWEEP) {
+		// every candidate: sort by centre, suffix boxes, sweep
+		uint32_t tmp[3][SAH_SWEEP];
+		HBox* suf = scratch.data();
+		for (int k = 0; k < 3; ++k) {
+			if (!(cmax[k] > cmin[k])) continue;
+			std::copy(idx.begin() + lo, idx.begin() + hi, tmp[k]);
+			std::stable_sort(tmp[k], tmp[k] + count, [&](uint32_t a, uint32_t b) { return centre(a, k) < centre(b, k); });
+			HBox acc; acc.clear();
+			for (int i = count - 1; i >= 1; --i) { acc.grow(&box[2 * (size_t)tmp[k][i]].x, &box[2 * (size_t)tmp[k][i] + 1].x); suf[i] = acc; }
+			acc.clear();
+			for (int i = 1; i < count; ++i) {
+				acc.grow(&box[2 * (size_t)tmp[k][i - 1]].x, &box[2 * (size_t)tmp[k][i - 1] + 1].x);
+				float cost = acc.half_area() * (float)i + suf[i].half_area() * (float)(count - i);
+				if (cost < best) { best = cost; best_axis = k; best_pos = i; }
+			}
+		}
+		if (best_axis < 0) return lo + count / 2;
+		std::copy(tmp[best_axis], tmp[best_axis] + count, idx.begin() + lo);
+		return lo + best_pos;
+	}
+	HBox* bins = scratch.data();              // [3][SAH_BINS]
+	HBox* suf = scratch.data() + 3 * SAH_BINS; // [SAH_BINS]
+	int cnt[3][SAH_BINS];
+	float scale[3];
+	for (int k = 0; k < 3; ++k) {
+		scale[k] = cmax[k] > cmin[k] ? (float)SAH_BINS / (cmax[k] - cmin[k]) : 0.0f;
+		for (int b = 0; b < SAH_BINS; ++b) { bins[k * SAH_BINS + b].clear(); cnt[k][b] = 0; }
+	}
+	auto bin_of = [&](uint32_t p, int k) { return std::min(SAH_BINS - 1, std::max(0, (int)((centre(p, k) - cmin[k]) * scale[k]))); };
+	for (int i = lo; i < hi; ++i) {
+		const uint32_t p = idx[i];
+		const float* mn = &box[2 * (size_t)p].x; const float* mx = &box[2 * (size_t)p + 1].x;
+		for (int k = 0; k < 3; ++k) {
+			if (scale[k] == 0.0f) continue;
+			int b = bin_of(p, k);
+			bins[k * SAH_BINS + b].grow(mn, mx); ++cnt[k][b];
+		}
+	}
+	for (int k = 0; k < 3; ++k) {
+		if (scale[k] == 0.0f) continue;
+		HBox acc; acc.clear();
+		for (int b = SAH_BINS - 1; b >= 1; --b) { if (cnt[k][b]) acc.grow(bins[k * SAH_BINS + b]); suf[b] = acc; }
+		acc.clear();
+		int nl = 0;
+		for (int b = 1; b < SAH_BINS; ++b) {
+			if (cnt[k][b - 1]) acc.grow(bins[k * SAH_BINS + b - 1]);
+			nl += cnt[k][b - 1];
+			if (nl == 0 || nl == count) continue;
+			float cost = acc.half_area() * (float)nl + suf[b].half_area() * (float)(count - nl);
+			if (cost < best) { best = cost; best_axis = k; best_pos = b; }
+		}
+	}
+	if (best_axis < 0) return lo + count / 2;   // all centres coincide
+	auto mid = std::partition(idx.begin() + lo, idx.begin() + hi, [&](uint32_t p) { return bin_of(p, best_axis) < best_pos; });
+	int m = (int)(mid - idx.begin());
+	return (m == lo || m == hi) ? lo + count / 2 : m;
+}
+
+}  // namespace
+
+static int build_sah_host(rt_hip_ctx* ctx, int n, float pad, uint32_t* d_order, int* d_left, int* d_right,
+                          int* d_node_parent, int* d_leaf_parent, BoxSlot* d_slots)
+{
+	hipStream_t st = ctx->stream;
+	std::vector<float4> box(2 * (size_t)n);
+	RT_HIP_CHECK(hipMemcpyAsync(box.data(), ctx->d_tri_box.p, box.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	std::vector<uint32_t> idx(n);
+	for (int i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+	std::vector<int> left(n - 1), right(n - 1), node_parent(n - 1), leaf_parent(n);
+	std::vector<HBox> scratch(4 * SAH_BINS);
+	struct Job { int lo, hi, parent, is_right; };
+	std::vector<Job> stack;
+	stack.push_back({0, n, -1, 0});
+	int next_id = 0;
+	while (!stack.empty()) {
+		const Job j = stack.back();
+		stack.pop_back();
+		const int id = next_id++;
+		node_parent[id] = j.parent;
+		if (j.parent >= 0) (j.is_right ? right : left)[j.parent] = id;
+		const int mid = (j.hi - j.lo == 2) ? j.lo + 1 : sah_split(box, idx, j.lo, j.hi, scratch);
+		// right first onto the stack, so the left subtree takes the next ids
+		if (j.hi - mid == 1) { right[id] = ~mid; leaf_parent[mid] = id; } else stack.push_back({mid, j.hi, id, 1});
+		if (mid - j.lo == 1) { left[id] = ~j.lo; leaf_parent[j.lo] = id; } else stack.push_back({j.lo, mid, id, 0});
+	}
+	if (next_id != n - 1) { rt_set_error("SAH build made %d nodes for %d triangles", next_id, n); return RT_HIP_ERR_STATE; }
+	// boxes: leaves padded like the device builders', internal nodes bottom-up (children have higher ids)
+	std::vector<BoxSlot> slots(2 * (size_t)n - 1);
+	for (int j = 0; j < n; ++j) {
+		const float4 a = box[2 * (size_t)idx[j]], b = box[2 * (size_t)idx[j] + 1];
+		BoxSlot& s = slots[(size_t)(n - 1) + j];
+		s.mn[0] = a.x - pad; s.mn[1] = a.y - pad; s.mn[2] = a.z - pad;
+		s.mx[0] = b.x + pad; s.mx[1] = b.y + pad; s.mx[2] = b.z + pad;
+	}
+	for (int i = n - 2; i >= 0; --i) {
+		const BoxSlot& l = left[i] >= 0 ? slots[left[i]] : slots[(size_t)(n - 1) + (~left[i])];
+		const BoxSlot& r = right[i] >= 0 ? slots[right[i]] : slots[(size_t)(n - 1) + (~right[i])];
+		for (int k = 0; k < 3; ++k) { slots[i].mn[k] = std::min(l.mn[k], r.mn[k]); slots[i].mx[k] = std::max(l.mx[k], r.mx[k]); }
+	}
+	RT_HIP_CHECK(hipMemcpyAsync(d_order, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipMemcpyAsync(d_left, left.data(), (size_t)(n - 1) * 4, hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipMemcpyAsync(d_right, right.data(), (size_t)(n - 1) * 4, hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipMemcpyAsync(d_node_parent, node_parent.data(), (size_t)(n - 1) * 4, hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipMemcpyAsync(d_leaf_parent, leaf_parent.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipMemcpyAsync(d_slots, slots.data(), slots.size() * sizeof(BoxSlot), hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));   // the host vectors die here
+	return RT_HIP_OK;
+}
+
 int rt_build_lbvh(rt_hip_ctx* ctx)
 {
 	hipStream_t st = ctx->stream;
@@ -484,13 +632,16 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 	for (int k = 0; k < 3; ++k) ext[k] = ctx->bounds[3 + k] - ctx->bounds[k];
 	float emax = std::max(std::max(ext[0], ext[1]), ext[2]);
 	if (!(emax > 0.0f)) emax = 1.0f;
-	// one cubic grid over the longest extent keeps cells isotropic
-	float s = 1.0f / emax;
-	hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), n, ctx->bounds[0],
-	                   ctx->bounds[1], ctx->bounds[2], s, s, s, keys, order);
-	RT_HIP_CHECK(hipGetLastError());
-	RT_CHECK(rt_radix_sort_pairs64(ctx, keys, ctx->d_morton_tmp.as<uint64_t>(), order,
-	                               ctx->d_order_tmp.as<uint32_t>(), n, 63));
+	const bool sah = ctx->cfg.accel == RT_HIP_ACCEL_SAH;
+	if (!sah) {
+		// one cubic grid over the longest extent keeps cells isotropic
+		float s = 1.0f / emax;
+		hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), n, ctx->bounds[0],
+		                   ctx->bounds[1], ctx->bounds[2], s, s, s, keys, order);
+		RT_HIP_CHECK(hipGetLastError());
+		RT_CHECK(rt_radix_sort_pairs64(ctx, keys, ctx->d_morton_tmp.as<uint64_t>(), order,
+		                               ctx->d_order_tmp.as<uint32_t>(), n, 63));
+	}
 
 	// topology arrays: left, right, node_parent (n-1 each), leaf_parent (n), arrive (n-1), depth (1)
 	size_t ints = (size_t)4 * n + 8;
@@ -508,7 +659,9 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 
 	float pad = 1e-5f * emax;
 	const bool ploc = ctx->cfg.accel == RT_HIP_ACCEL_PLOC || (ctx->cfg.accel == RT_HIP_ACCEL_AUTO && rt_auto_ploc());
-	if (ploc) {
+	if (sah) {
+		RT_CHECK(build_sah_host(ctx, n, pad, order, left, right, node_parent, leaf_parent, slots));
+	} else if (ploc) {
 		RT_CHECK(build_ploc(ctx, n, pad, order, left, right, node_parent, leaf_parent, slots));
 	} else {
 		hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, st, keys, n, left, right, node_parent, leaf_parent);

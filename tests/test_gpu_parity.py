@@ -32,7 +32,7 @@ def rt():
 
 
 @pytest.mark.parametrize("scene_fn", [scenes.cornell, lambda: scenes.atrium(2048)], ids=["cornell", "atrium2k"])
-@pytest.mark.parametrize("accel", [1, 2, 3], ids=["brute", "lbvh", "ploc"])
+@pytest.mark.parametrize("accel", [1, 2, 3, 4], ids=["brute", "lbvh", "ploc", "sah"])
 def test_array_intersect(rt, oracle_cls, scene_fn, accel):
     sc = scene_fn()
     orc = oracle_cls(sc)
@@ -133,7 +133,7 @@ def test_process_rays_cornell(rt, oracle_cls, accel):
     g.close()
 
 
-@pytest.mark.parametrize("accel", [2, 3], ids=["lbvh", "ploc"])
+@pytest.mark.parametrize("accel", [2, 3, 4], ids=["lbvh", "ploc", "sah"])
 def test_process_rays_atrium_lbvh(rt, oracle_cls, accel):
     sc = scenes.atrium(8192)
     orc = oracle_cls(sc)
@@ -177,8 +177,8 @@ def test_process_rays_edge_cases(rt, oracle_cls):
     g.close()
 
 
-@pytest.mark.parametrize("accel,tris", [(2, 8192), (3, 8192), (3, 700), (3, 40000)],
-                         ids=["lbvh", "ploc", "ploc-one-workgroup", "ploc-40k"])
+@pytest.mark.parametrize("accel,tris", [(2, 8192), (3, 8192), (3, 700), (3, 40000), (4, 8192), (4, 40000)],
+                         ids=["lbvh", "ploc", "ploc-one-workgroup", "ploc-40k", "sah", "sah-40k"])
 def test_bvh_structure(rt, accel, tris):
     sc = scenes.atrium(tris)
     g = rt.RtHip(sc, accel=accel)
@@ -406,7 +406,7 @@ def test_shade_results(rt, oracle_cls, scene_fn):
 
 
 # ---- incoherent stress set: random origins and directions, BVH vs exhaustive search ----
-@pytest.mark.parametrize("accel", [2, 3], ids=["lbvh", "ploc"])
+@pytest.mark.parametrize("accel", [2, 3, 4], ids=["lbvh", "ploc", "sah"])
 @pytest.mark.parametrize("spread", [1.0, 12.0], ids=["inside", "far-origins"])
 def test_incoherent_rays_bvh_equals_exhaustive(rt, accel, spread):
     """The box test only culls: it works on 16-bit outward-rounded boxes with one FMA per plane and
