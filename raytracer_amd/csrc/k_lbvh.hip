@@ -393,8 +393,8 @@ __global__ __launch_bounds__(256) void k_emit_nodes(const BoxSlot* __restrict__ 
 		rq[k] = quant_lo(r->mn[k], qf.org[k], qf.scale[k]); rq[3 + k] = quant_hi(r->mx[k], qf.org[k], qf.scale[k]);
 	}
 	QNode qn;
-	qn.w0 = make_uint4(lq[0] | lq[1] << 16, lq[2] | lq[3] << 16, lq[4] | lq[5] << 16, rq[0] | rq[1] << 16);
-	qn.w1 = make_uint4(rq[2] | rq[3] << 16, rq[4] | rq[5] << 16, (uint32_t)lc, (uint32_t)rc);
+	qn.w0 = make_uint4(lq[0] | lq[3] << 16, lq[1] | lq[4] << 16, lq[2] | lq[5] << 16, rq[0] | rq[3] << 16);
+	qn.w1 = make_uint4(rq[1] | rq[4] << 16, rq[2] | rq[5] << 16, (uint32_t)lc, (uint32_t)rc);
 	qnodes[i] = qn;
 }
 

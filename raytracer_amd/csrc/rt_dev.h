@@ -59,8 +59,9 @@ static_assert(sizeof(BvhNode) == 64, "BVH node is one 64-byte line");
 // kernels are bound by the vector-memory pipeline (TA/TD 81-87 % busy with 64-byte nodes,
 // profiles/), not by HBM or the VALU; halving the bytes per visit is what moves them.  The float
 // nodes (BvhNode) remain the build's output and what rt_hip_get_bvh returns.
-//   w0 = (l.min.x | l.min.y << 16, l.min.z | l.max.x << 16, l.max.y | l.max.z << 16, r.min.x | r.min.y << 16)
-//   w1 = (r.min.z | r.max.x << 16, r.max.y | r.max.z << 16, bits left, bits right)
+// A plane pair (min | max << 16) per axis and child, so that one rotate by 0 or 16 bits puts the plane
+// the ray enters through in the low half-word:
+//   w0 = (l.x, l.y, l.z, r.x)   w1 = (r.y, r.z, bits left, bits right)      with  c.k = c.min.k | c.max.k << 16
 struct __attribute__((aligned(32))) QNode {
 	uint4 w0, w1;
 };
@@ -198,14 +199,16 @@ __device__ __forceinline__ bool mt_occlude_ref(f3 O, f3 D, f3 v0, f3 e1, f3 e2, 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Ray constants for the slab test against quantised planes: t = q * a + b with a = scale / d and
-// b = (org - o) / d, paired the way the node's 12 values pair up ((x,y) (z,x) (y,z)) so that the 12
-// multiply-adds of a node visit issue as 6 packed-FP32 FMAs.  The one rounding of the FMA against
-// terms of magnitude |org - o| / |d| displaces a plane by at most ~1e-7 of the scene extent, which
-// the 1e-5-extent padding of the boxes at build time covers (as does the outward rounding of the
-// 16-bit grid); |d| < 1e-20 is replaced by +-1e-20 before inversion (no inf, no 0 * inf NaN).
+// b = (org - o) / d, one packed-FP32 FMA per (min, max) plane pair, 6 per node visit.  The one rounding
+// of the FMA against terms of magnitude |org - o| / |d| displaces a plane by at most ~1e-7 of the scene
+// extent, which the 1e-5-extent padding of the boxes at build time covers (as does the outward rounding
+// of the 16-bit grid); |d| < 1e-20 is replaced by +-1e-20 before inversion (no inf, no 0 * inf NaN).
+// rot = 16 where d < 0: the pair is rotated before unpacking so that its low half is the entry plane.
+// fma(q, a, b) is monotone in q, so for a > 0 the min plane's t is the smaller one (and the larger for
+// a < 0): choosing by the sign of d gives exactly min / max of the two, without computing them.
 struct RayPre {
-	v2f a_xy, a_zx, a_yz;
-	v2f b_xy, b_zx, b_yz;
+	float ax, ay, az, bx, by, bz;
+	uint32_t rx, ry, rz;
 };
 
 __device__ __forceinline__ float safe_rcp(float d)
@@ -220,31 +223,31 @@ __device__ __forceinline__ RayPre ray_pre(const QFrame& qf, f3 o, f3 d)
 {
 	RayPre r;
 	const float ix = safe_rcp(d.x), iy = safe_rcp(d.y), iz = safe_rcp(d.z);
-	const float ax = qf.scale[0] * ix, ay = qf.scale[1] * iy, az = qf.scale[2] * iz;
-	const float bx = (qf.org[0] - o.x) * ix, by = (qf.org[1] - o.y) * iy, bz = (qf.org[2] - o.z) * iz;
-	r.a_xy = mk2(ax, ay); r.a_zx = mk2(az, ax); r.a_yz = mk2(ay, az);
-	r.b_xy = mk2(bx, by); r.b_zx = mk2(bz, bx); r.b_yz = mk2(by, bz);
+	r.ax = qf.scale[0] * ix; r.ay = qf.scale[1] * iy; r.az = qf.scale[2] * iz;
+	r.bx = (qf.org[0] - o.x) * ix; r.by = (qf.org[1] - o.y) * iy; r.bz = (qf.org[2] - o.z) * iz;
+	r.rx = (__float_as_uint(ix) >> 31) << 4; r.ry = (__float_as_uint(iy) >> 31) << 4; r.rz = (__float_as_uint(iz) >> 31) << 4;
 	return r;
 }
 
 __device__ __forceinline__ v2f unpack16(uint32_t w) { return mk2((float)(w & 0xffffu), (float)(w >> 16)); }
 __device__ __forceinline__ v2f fma2(v2f q, v2f a, v2f b) { return __builtin_elementwise_fma(q, a, b); }
+// (t at the entry plane, t at the exit plane) of one axis
+__device__ __forceinline__ v2f slab_axis(uint32_t w, uint32_t rot, float a, float b)
+{
+	return fma2(unpack16(__builtin_amdgcn_alignbit(w, w, rot)), mk2(a, a), mk2(b, b));
+}
 
-// Both child boxes of a node against one ray.  Hit iff the widened slab interval intersects
-// [0, tlimit]; entry distances in tl / tr.
+// Both child boxes of a node against one ray.  Hit iff the slab interval intersects [0, tlimit]; entry
+// distances in tl / tr.
 __device__ __forceinline__ void slab2(const RayPre& r, uint4 w0, uint4 w1, float tlimit, bool& hl, bool& hr,
                                       float& tl, float& tr)
 {
-	v2f a = fma2(unpack16(w0.x), r.a_xy, r.b_xy);  // l: x0 y0
-	v2f b = fma2(unpack16(w0.y), r.a_zx, r.b_zx);  // l: z0 x1
-	v2f c = fma2(unpack16(w0.z), r.a_yz, r.b_yz);  // l: y1 z1
-	v2f d = fma2(unpack16(w0.w), r.a_xy, r.b_xy);  // r: x0 y0
-	v2f e = fma2(unpack16(w1.x), r.a_zx, r.b_zx);  // r: z0 x1
-	v2f f = fma2(unpack16(w1.y), r.a_yz, r.b_yz);  // r: y1 z1
-	float tnl = fmaxf(fmaxf(fminf(a.x, b.y), fminf(a.y, c.x)), fmaxf(fminf(b.x, c.y), 0.0f));
-	float tfl = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fmaxf(b.x, c.y));
-	float tnr = fmaxf(fmaxf(fminf(d.x, e.y), fminf(d.y, f.x)), fmaxf(fminf(e.x, f.y), 0.0f));
-	float tfr = fminf(fminf(fmaxf(d.x, e.y), fmaxf(d.y, f.x)), fmaxf(e.x, f.y));
+	const v2f lx = slab_axis(w0.x, r.rx, r.ax, r.bx), ly = slab_axis(w0.y, r.ry, r.ay, r.by), lz = slab_axis(w0.z, r.rz, r.az, r.bz);
+	const v2f qx = slab_axis(w0.w, r.rx, r.ax, r.bx), qy = slab_axis(w1.x, r.ry, r.ay, r.by), qz = slab_axis(w1.y, r.rz, r.az, r.bz);
+	const float tnl = fmaxf(fmaxf(lx.x, ly.x), fmaxf(lz.x, 0.0f));
+	const float tfl = fminf(fminf(lx.y, ly.y), lz.y);
+	const float tnr = fmaxf(fmaxf(qx.x, qy.x), fmaxf(qz.x, 0.0f));
+	const float tfr = fminf(fminf(qx.y, qy.y), qz.y);
 	// No multiplicative widening of [tn, tf]: every rounding in t = fma(q, a, b) displaces a plane by
 	// less than 3e-7 x (extent + |origin - scene|), and the boxes carry an absolute pad of 1e-5 x extent
 	// (plus the outward rounding of the grid), which covers it for origins within ~30 extents.
