@@ -1382,15 +1382,16 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		if (hi <= lo && !q_count) return RT_HIP_OK;
 		const size_t lds = rt_trace_lds(sv, TRACE_BLOCK);
 		const int blocks = rt_trace_blocks(ctx, std::max<int64_t>((int64_t)n * (hi - lo), n), TRACE_BLOCK);
-		RT_CHECK(rt_begin_trace_timing(ctx));
+		// timed (profile mode) through the dispatch itself: no event markers between the frame's kernels
+		hipEvent_t t0, t1;
+		RT_CHECK(rt_next_trace_events(ctx, 1, &t0, &t1));
 		if (cen)
-			hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(TRACE_BLOCK), lds, st, sv, geo, n, n_ptr, lo, hi,
-			                   ctx->cfg.shadow_t_max, occl, cen, fq);
+			hipExtLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(TRACE_BLOCK), (uint32_t)lds, st, t0, t1, 0u, sv, geo, n, n_ptr, lo, hi,
+			                      ctx->cfg.shadow_t_max, occl, cen, fq);
 		else
-			hipLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(TRACE_BLOCK), lds, st, sv, geo, n, n_ptr, lo, hi,
-			                   ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr, fq);
+			hipExtLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(TRACE_BLOCK), (uint32_t)lds, st, t0, t1, 0u, sv, geo, n, n_ptr, lo, hi,
+			                      ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr, fq);
 		RT_HIP_CHECK(hipGetLastError());
-		RT_CHECK(rt_end_trace_timing(ctx, 1));
 		return RT_HIP_OK;
 	};
 	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));

@@ -168,6 +168,29 @@ int rt_end_trace_timing(rt_hip_ctx* ctx, int cls, hipStream_t st)
 	return RT_HIP_OK;
 }
 
+// The event pair for ONE launch timed through its own dispatch packet (hipExtLaunchKernelGGL takes the
+// kernel's start and end time stamps from the packet's completion signal): unlike hipEventRecord before and
+// after, nothing is queued between the kernels (each recorded event cost ~6 us of idle GPU in the frame's
+// timeline).  Both null when profiling is off.
+int rt_next_trace_events(rt_hip_ctx* ctx, int cls, hipEvent_t* a, hipEvent_t* b)
+{
+	*a = *b = nullptr;
+	if (cls) ctx->stats.any_launches += 1; else ctx->stats.closest_launches += 1;
+	if (!ctx->cfg.profile) return RT_HIP_OK;
+	if (ctx->trace_events_used == ctx->trace_events.size()) {
+		hipEvent_t x, y;
+		RT_HIP_CHECK(hipEventCreate(&x));
+		RT_HIP_CHECK(hipEventCreate(&y));
+		ctx->trace_events.push_back(std::make_pair(x, y));
+		ctx->trace_event_class.push_back(0);
+	}
+	*a = ctx->trace_events[ctx->trace_events_used].first;
+	*b = ctx->trace_events[ctx->trace_events_used].second;
+	ctx->trace_event_class[ctx->trace_events_used] = cls;
+	++ctx->trace_events_used;
+	return RT_HIP_OK;
+}
+
 unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls)
 {
 	if (!ctx->cfg.census) return nullptr;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
@@ -170,6 +171,7 @@ int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block);
 size_t rt_trace_lds(const SceneView& sv, int block);  // RT_HIP_EXTRA_LDS (bytes): occupancy experiments only
 int rt_begin_trace_timing(rt_hip_ctx* ctx, hipStream_t st = nullptr);  // nullptr: ctx->stream
 int rt_end_trace_timing(rt_hip_ctx* ctx, int cls, hipStream_t st = nullptr);
+int rt_next_trace_events(rt_hip_ctx* ctx, int cls, hipEvent_t* a, hipEvent_t* b);  // for hipExtLaunchKernelGGL
 unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls);  // nullptr unless cfg.census
 int rt_collect_timing(rt_hip_ctx* ctx);
 int rt_ensure_pinned(void** p, size_t* cap, size_t bytes);
