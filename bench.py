@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+NODE_FLOP, TRI_FLOP = 34.0, 45.0   # per node visit: 12 FMA (24) + 8 min/max + 2 compares; per triangle test: Moeller-Trumbore up to t
 NODE_BYTES = 32.0  # the traversal reads 32-byte quantised nodes (rt_dev.h: QNode); SURVEY 8d prices the float node at 64
 VALU_PEAK_TFLOPS = 78.6  # per-lane v_fma_f32 rate (157 TFLOP/s needs packed/dual-issue FP32 throughout)
 
@@ -284,10 +285,10 @@ def main():
                 "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_traffic.json); the "
                                 "algorithmic bytes are served by L1/L2/Infinity Cache, so achieved > peak is expected and HBM "
                                 "is not the binding limit: see `valu`",
-                "valu": {"unit": "TFLOP/s", "flop_per_ray": round(48.0 * nodes_dom + 45.0 * tris_dom, 1),
-                         "achieved": round(rays_per_launch * (48.0 * nodes_dom + 45.0 * tris_dom) / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0,
+                "valu": {"unit": "TFLOP/s", "flop_per_ray": round(NODE_FLOP * nodes_dom + TRI_FLOP * tris_dom, 1),
+                         "achieved": round(rays_per_launch * (NODE_FLOP * nodes_dom + TRI_FLOP * tris_dom) / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0,
                          "peak": VALU_PEAK_TFLOPS,
-                         "frac": round(rays_per_launch * (48.0 * nodes_dom + 45.0 * tris_dom) / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4) if avg_ms > 0 else 0.0},
+                         "frac": round(rays_per_launch * (NODE_FLOP * nodes_dom + TRI_FLOP * tris_dom) / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4) if avg_ms > 0 else 0.0},
                 "kernel": dominant, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": round(rays_per_launch, 1),
                 "nodes_per_ray": round(nodes_dom, 2), "tris_per_ray": round(tris_dom, 2),
                 "bytes_per_ray": round(bpr, 1),

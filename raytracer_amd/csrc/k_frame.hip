@@ -14,7 +14,9 @@
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int TRACE_BLOCK = 128;
+// one wave per workgroup for the kernels that traverse: the frame measured 1.145 ms at 64, 1.173 at 128, 1.193 at 256
+// (a finished wave frees its slot and its LDS stack at once instead of waiting for its block mates)
+constexpr int TRACE_BLOCK = 64;
 inline int nblocks(int64_t n, int b) { return (int)((n + b - 1) / b); }
 
 // Resolved hit: what IAccel::intersect leaves in the Ray plus the material.

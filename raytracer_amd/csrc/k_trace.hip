@@ -12,7 +12,7 @@
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int BVH_BLOCK = 128;
+constexpr int BVH_BLOCK = 64;
 
 // ---- brute force ------------------------------------------------------------------------------
 // One ray per lane; the triangle index is wave-uniform, so the 48-byte records come in through

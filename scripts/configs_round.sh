@@ -7,6 +7,8 @@ run atrium-1m-1080p --workload atrium-1m-1080p
 run atrium-1m-4k --workload atrium-1m-4k
 run cornell-1080p --workload cornell-1080p
 run lbvh --accel lbvh
+run sah --accel sah
+run sah-atrium-1m-1080p --accel sah --workload atrium-1m-1080p
 run literal --shadow-mode literal
 run inflight-2 --inflight 2
 python - <<'PY'
