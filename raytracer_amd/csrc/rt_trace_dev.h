@@ -35,6 +35,7 @@ __device__ __forceinline__ int stack_pop(const SceneView& sv, const lds_int* sta
 // balancing of uneven rays to the hardware dispatcher.  Measured on MI355X (atrium-262k, shadow
 // rays): 1x 0.765 ms, 2x 0.657 ms, 4x 0.586 ms, uncapped 0.594 ms; a software queue (one returning
 // atomic per wave per 64 rays) was atomic-bound at 1.08 ms.
+// Above the cap the grid is sized so that every thread makes the same number of rounds (rt_trace_blocks).
 // XCD-aware block order: workgroups are dealt round robin to the 8 XCDs (block b runs on XCD
 // b % 8), each with an L2 of its own.  Renumbering b -> (b % 8) * ceil(nb / 8) + b / 8 hands every
 // XCD one contiguous eighth of each grid-sized slice of the items, so that its L2 holds the part of
