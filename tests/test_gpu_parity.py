@@ -647,3 +647,53 @@ def test_scene_update_equals_fresh_build(rt, oracle_cls):
         np.testing.assert_array_equal(hit, a_["tidx"] != MISS)
         assert_bits_equal(o["t"][hit], a_["t"][hit], "t vs oracle")
     g.close()
+
+
+def test_stack_spill_path(rt, monkeypatch):
+    """RT_HIP_LDS_DEPTH=2: all but two entries of every lane's traversal stack live in the HBM overflow
+    array.  Closest hits must still equal the exhaustive search bit for bit, any-hit must agree with it,
+    and a frame must equal the one rendered with the default split."""
+    torch = _torch()
+    sc = scenes.atrium(8192)
+    rng = np.random.RandomState(5)
+    n = 1 << 15
+    allv = np.concatenate([m.verts for m in sc.meshes], 0)
+    lo, hi = allv.min(0), allv.max(0)
+    o = (lo + rng.uniform(0, 1, (n, 3)) * (hi - lo)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays = np.concatenate([o, d], 1)
+    ref = rt.RtHip(sc, semantics="array", accel=1)
+    a = ref.intersect(rays)
+    ref.close()
+
+    def frame(g):
+        w, h = 96, 64
+        d_n = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+        d_p = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+        g.render_gbuffer_device(sc.fov, w, h, d_n, d_p)
+        out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+        g.render_frame_device(d_p, d_n, w, h, out)
+        return out.cpu().numpy()
+
+    g = rt.RtHip(sc, semantics="array", accel=3, bounces=2, do_shadows=1, shadow_t_max=1.0)
+    assert g.stats()["bvh_depth"] > 8
+    f_default = frame(g)
+    g.close()
+    monkeypatch.setenv("RT_HIP_LDS_DEPTH", "2")
+    g = rt.RtHip(sc, semantics="array", accel=3, bounces=2, do_shadows=1, shadow_t_max=1.0)
+    b = g.intersect(rays)
+    d_o, d_d = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    d_hits = torch.zeros(n * 4, dtype=torch.float32, device="cuda")
+    d_occ = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    g.trace_closest_device(d_o, d_d, n, d_hits)
+    g.trace_any_device(d_o, d_d, n, d_occ)
+    f_spill = frame(g)
+    g.close()
+    np.testing.assert_array_equal(a["hit"], b["hit"])
+    hit = a["hit"] > 0
+    assert hit.sum() > n // 4
+    np.testing.assert_array_equal(a["hits"]["prim"][hit], b["hits"]["prim"][hit])
+    assert_bits_equal(a["hits"]["t"][hit], b["hits"]["t"][hit], "t")
+    # any-hit through the same spilled stack: occluded <=> a closest hit exists below t_max
+    assert torch.equal(d_occ > 0, d_hits.view(torch.int32).view(-1, 4)[:, 0] != -1)
+    np.testing.assert_array_equal(f_default, f_spill)
