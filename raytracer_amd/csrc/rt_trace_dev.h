@@ -7,7 +7,7 @@
 // Traverse the LBVH for one ray.  `stack` points at this lane's column of an LDS array laid out
 // [lds_depth][block_threads] (so that every ds_read/ds_write of a wave touches 64 consecutive dwords
 // -> conflict free), `stride` = threads per block.  Only the first sv.lds_depth entries of a lane's
-// stack live in LDS (3 KB per wave at depth 12, so the full 32 waves/CU stay resident); deeper
+// stack live in LDS (4 KB per wave at the default depth 16, so the full 32 waves/CU stay resident); deeper
 // entries -- rare -- go to `spill`, this thread's column of an HBM array [..][sv.spill_stride].
 //   ANY = false: closest hit into `best` (prim = RT_MISS / t = +inf on a miss); returns hit?
 //   ANY = true : first accepted hit terminates; returns occluded?
