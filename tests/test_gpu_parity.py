@@ -697,3 +697,67 @@ def test_stack_spill_path(rt, monkeypatch):
     # any-hit through the same spilled stack: occluded <=> a closest hit exists below t_max
     assert torch.equal(d_occ > 0, d_hits.view(torch.int32).view(-1, 4)[:, 0] != -1)
     np.testing.assert_array_equal(f_default, f_spill)
+
+
+def _soup_scene(name, tris):
+    """One mesh from a (n, 3, 3) array of triangle corners (vertices not shared)."""
+    tris = np.asarray(tris, np.float32)
+    n = tris.shape[0]
+    verts = tris.reshape(-1, 3)
+    nrm = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (3 * n, 1))
+    uv = np.zeros((3 * n, 2), np.float32)
+    faces = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    mesh = scenes._mesh(verts, nrm, uv, faces, 0)
+    return scenes.Scene(name=name, materials=[scenes.Material(diffuse=(200.0, 200.0, 200.0))], meshes=[mesh],
+                        lights=[scenes.Light(position=(0.0, 5.0, 0.0))])
+
+
+def _degenerate_cases():
+    rng = np.random.RandomState(4)
+    one = np.array([[-1.0, -1.0, -5.0], [1.0, -1.0, -5.0], [0.0, 1.0, -5.0]], np.float32)
+    cases = {}
+    cases["two"] = np.stack([one, one + np.array([0.5, 0.0, -1.0], np.float32)])
+    cases["three"] = np.stack([one, one + np.array([0.5, 0.0, -1.0], np.float32), one + np.array([-0.5, 0.3, 1.0], np.float32)])
+    # 300 copies of one triangle (identical boxes and centres: exact ties everywhere) + 20 others
+    others = one[None] * 0.3 + rng.uniform(-2, 2, (20, 1, 3)).astype(np.float32) + np.array([0, 0, -5], np.float32)
+    cases["duplicates"] = np.concatenate([np.repeat(one[None], 300, 0), others])
+    # everything in the plane z = -6 (the scene box is flat on one axis), every fifth triangle with zero area
+    g = rng.uniform(-3, 3, (400, 3, 3)).astype(np.float32) * 0.2 + rng.uniform(-3, 3, (400, 1, 3)).astype(np.float32)
+    g[:, :, 2] = -6.0
+    g[::5, 2] = g[::5, 1]
+    cases["flat-with-zero-area"] = g
+    # slivers along one axis: boxes that overlap almost completely
+    s = np.zeros((256, 3, 3), np.float32)
+    s[:, 0] = [-4.0, 0.0, -7.0]; s[:, 1] = [4.0, 0.0, -7.0]
+    s[:, 2, 0] = 0.0; s[:, 2, 1] = 1e-3; s[:, 2, 2] = -7.0
+    s[:, :, 1] += np.linspace(-2, 2, 256, dtype=np.float32)[:, None]
+    cases["slivers"] = s
+    return cases
+
+
+@pytest.mark.parametrize("accel", [2, 3, 4], ids=["lbvh", "ploc", "sah"])
+@pytest.mark.parametrize("case", ["two", "three", "duplicates", "flat-with-zero-area", "slivers"])
+def test_bvh_degenerate_geometry(rt, accel, case):
+    """Tiny scenes, exact duplicates (the lowest primitive id must win the tie, as in the exhaustive search), a flat
+    scene box, zero-area triangles, heavily overlapping slivers: every builder against brute force, bit for bit."""
+    tris = _degenerate_cases()[case]
+    sc = _soup_scene(case, tris)
+    rng = np.random.RandomState(9)
+    n = 1 << 13
+    o = np.tile(np.array([[0.0, 0.0, 0.0]], np.float32), (n, 1)) + rng.normal(0, 0.05, (n, 3)).astype(np.float32)
+    target = tris.reshape(-1, 3)[rng.randint(0, tris.shape[0] * 3, n)] + rng.normal(0, 0.3, (n, 3)).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    rays = np.concatenate([o, d], 1)
+    ref = rt.RtHip(sc, semantics="array", accel=1)
+    a = ref.intersect(rays)
+    ref.close()
+    g = rt.RtHip(sc, semantics="array", accel=accel)
+    st = g.stats()
+    assert st["num_nodes"] == st["num_tris"] - 1 == tris.shape[0] - 1
+    b = g.intersect(rays)
+    g.close()
+    np.testing.assert_array_equal(a["hit"], b["hit"])
+    hit = a["hit"] > 0
+    assert hit.sum() > 100    # the slivers are 1e-3 wide: few rays hit them
+    np.testing.assert_array_equal(a["hits"]["prim"][hit], b["hits"]["prim"][hit])
+    assert_bits_equal(a["hits"]["t"][hit], b["hits"]["t"][hit], "t")
