@@ -675,6 +675,7 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 		ctx->qframe.org[k] = ctx->bounds[k] - 2.0f * pad;
 		float e = (ctx->bounds[3 + k] + 2.0f * pad) - ctx->qframe.org[k];
 		ctx->qframe.scale[k] = e > 0.0f ? e / 65535.0f : 1.0f;
+		ctx->qframe.reach[k] = std::fabs(ctx->qframe.org[k]) + 65535.0f * ctx->qframe.scale[k];
 	}
 	hipLaunchKernelGGL(k_emit_nodes, dim3(g), dim3(256), 0, st, slots, n, left, right, node_parent,
 	                   ctx->d_nodes.as<BvhNode>(), ctx->qframe, ctx->d_qnodes.as<QNode>());

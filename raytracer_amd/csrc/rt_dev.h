@@ -70,6 +70,7 @@ static_assert(sizeof(QNode) == 32, "quantised node is half a BvhNode");
 struct QFrame {  // plane = org + q * scale, per axis
 	float org[3];
 	float scale[3];
+	float reach[3];  // |org| + 65535 * scale: the largest |plane coordinate| of the axis (error bound of the slab test)
 };
 
 // 48-byte intersection record in leaf (Morton) order: the M-T operands, nothing else.
@@ -207,7 +208,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // fma(q, a, b) is monotone in q, so for a > 0 the min plane's t is the smaller one (and the larger for
 // a < 0): choosing by the sign of d gives exactly min / max of the two, without computing them.
 struct RayPre {
-	float ax, ay, az, bx, by, bz;
+	float ax, ay, az;
+	v2f bx, by, bz;     // (b - delta, b + delta): entry planes a little earlier, exit planes a little later
 	uint32_t rx, ry, rz;
 };
 
@@ -224,7 +226,15 @@ __device__ __forceinline__ RayPre ray_pre(const QFrame& qf, f3 o, f3 d)
 	RayPre r;
 	const float ix = safe_rcp(d.x), iy = safe_rcp(d.y), iz = safe_rcp(d.z);
 	r.ax = qf.scale[0] * ix; r.ay = qf.scale[1] * iy; r.az = qf.scale[2] * iz;
-	r.bx = (qf.org[0] - o.x) * ix; r.by = (qf.org[1] - o.y) * iy; r.bz = (qf.org[2] - o.z) * iz;
+	const float bx = (qf.org[0] - o.x) * ix, by = (qf.org[1] - o.y) * iy, bz = (qf.org[2] - o.z) * iz;
+	// delta = 2^-21 x the largest magnitude that enters t = q * a + b on this axis (|b|, and the plane and
+	// origin coordinates over |d|): a few ulps of every rounding between the float planes the build
+	// compared against and this t, whatever the distance of the ray's origin or of the scene from 0.
+	const float eps = 4.76837158203125e-07f;
+	const float ex = __builtin_fmaf(fabsf(ix), qf.reach[0] + fabsf(o.x), fabsf(bx)) * eps;
+	const float ey = __builtin_fmaf(fabsf(iy), qf.reach[1] + fabsf(o.y), fabsf(by)) * eps;
+	const float ez = __builtin_fmaf(fabsf(iz), qf.reach[2] + fabsf(o.z), fabsf(bz)) * eps;
+	r.bx = mk2(bx - ex, bx + ex); r.by = mk2(by - ey, by + ey); r.bz = mk2(bz - ez, bz + ez);
 	r.rx = (__float_as_uint(ix) >> 31) << 4; r.ry = (__float_as_uint(iy) >> 31) << 4; r.rz = (__float_as_uint(iz) >> 31) << 4;
 	return r;
 }
@@ -232,9 +242,9 @@ __device__ __forceinline__ RayPre ray_pre(const QFrame& qf, f3 o, f3 d)
 __device__ __forceinline__ v2f unpack16(uint32_t w) { return mk2((float)(w & 0xffffu), (float)(w >> 16)); }
 __device__ __forceinline__ v2f fma2(v2f q, v2f a, v2f b) { return __builtin_elementwise_fma(q, a, b); }
 // (t at the entry plane, t at the exit plane) of one axis
-__device__ __forceinline__ v2f slab_axis(uint32_t w, uint32_t rot, float a, float b)
+__device__ __forceinline__ v2f slab_axis(uint32_t w, uint32_t rot, float a, v2f b)
 {
-	return fma2(unpack16(__builtin_amdgcn_alignbit(w, w, rot)), mk2(a, a), mk2(b, b));
+	return fma2(unpack16(__builtin_amdgcn_alignbit(w, w, rot)), mk2(a, a), b);
 }
 
 // Both child boxes of a node against one ray.  Hit iff the slab interval intersects [0, tlimit]; entry
@@ -248,9 +258,8 @@ __device__ __forceinline__ void slab2(const RayPre& r, uint4 w0, uint4 w1, float
 	const float tfl = fminf(fminf(lx.y, ly.y), lz.y);
 	const float tnr = fmaxf(fmaxf(qx.x, qy.x), fmaxf(qz.x, 0.0f));
 	const float tfr = fminf(fminf(qx.y, qy.y), qz.y);
-	// No multiplicative widening of [tn, tf]: every rounding in t = fma(q, a, b) displaces a plane by
-	// less than 3e-7 x (extent + |origin - scene|), and the boxes carry an absolute pad of 1e-5 x extent
-	// (plus the outward rounding of the grid), which covers it for origins within ~30 extents.
+	// No multiplicative widening of [tn, tf] here: the rounding of t = fma(q, a, b) is covered by the delta
+	// folded into b (ray_pre), on top of the build-time pad of 1e-5 x extent and the outward rounding of the grid.
 	tl = tnl; tr = tnr;
 	hl = tnl <= fminf(tfl, tlimit);
 	hr = tnr <= fminf(tfr, tlimit);
