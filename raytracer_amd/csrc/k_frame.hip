@@ -358,7 +358,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
 {
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
-	int* spill = sv.spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x);
 	grid_for_each(sv, tile8_count(w, h), [&](int64_t j) {
 		const int i = tile8_pixel((int)j, w, h);
 		if (i < 0) return;
@@ -386,7 +385,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_primary_gbuffer(SceneView sv, f
 			}
 		} else {
 			Hit best;
-			scene_trace<false>(sv, O, D, best, stack, TRACE_BLOCK, spill);
+			scene_trace<false>(sv, O, D, best, stack, TRACE_BLOCK);
 			if (best.prim != RT_MISS) {
 				HitInfo hi;
 				resolve_tri(sv, best, hi, uv ? tc : nullptr);
@@ -579,7 +578,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 	n = dev_count(n, n_ptr);
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
-	int* spill = sv.spill + ((int64_t)blockIdx.x * TRACE_BLOCK + threadIdx.x);
 	if (fq.org) {
 		const int nq = dev_count(fq.capacity, fq.count_ptr);
 		uint32_t cn = 0, ct = 0, rays = 0;
@@ -587,7 +585,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 			f3 O = ld3(fq.org + 3 * (size_t)i), D = ld3(fq.dir + 3 * (size_t)i);
 			Hit best;
 			uint32_t a = 0, b = 0;
-			if (sv.use_bvh) bvh_trace<false, CENSUS>(sv, O, D, best, stack, TRACE_BLOCK, spill, a, b);
+			if (sv.use_bvh) bvh_trace<false, CENSUS>(sv, O, D, best, stack, TRACE_BLOCK, a, b);
 			else brute_trace<false>(sv, O, D, best);
 			cn += a; ct += b; ++rays;
 			fq.hits[i] = best;
@@ -613,7 +611,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 		} else if (sv.use_bvh) {
 			Hit best;
 			uint32_t a = 0, b = 0;
-			blocked = bvh_trace<true, CENSUS>(sv, O, L, best, stack, TRACE_BLOCK, spill, a, b);
+			blocked = bvh_trace<true, CENSUS>(sv, O, L, best, stack, TRACE_BLOCK, a, b);
 			cn += a; ct += b;
 		} else {
 			Hit best;

@@ -52,7 +52,6 @@ __global__ __launch_bounds__(BLOCK) void k_photon_emit(SceneView sv, int per_lig
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	const int64_t gtid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
 	const int64_t gsize = (int64_t)gridDim.x * BLOCK;
-	int* spill = sv.spill + gtid;
 	for (int64_t k = gtid; k < count; k += gsize) {
 	int64_t idx = first + k;
 	int light = (int)(idx / per_light);
@@ -77,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) void k_photon_emit(SceneView sv, int per_lig
 	// emit_photon(): `pass++` hands the OLD value down, so every level runs with pass == 0 (:66)
 	for (int depth = 0; depth < (1 << 20); ++depth) {
 		Hit best;
-		scene_trace<false>(sv, origin, dir, best, RT_LDS_STACK(smem) + threadIdx.x, BLOCK, spill);
+		scene_trace<false>(sv, origin, dir, best, RT_LDS_STACK(smem) + threadIdx.x, BLOCK);
 		if (best.prim == RT_MISS) break;
 		const TriPos tp = sv.tri_pos[best.prim];
 		const TriAttr ta = sv.tri_attr[best.prim];

@@ -60,14 +60,13 @@ __global__ __launch_bounds__(BVH_BLOCK) void k_bvh(SceneView sv, const float* __
 	// Capped grid (see grid_for_each); a thread's overflow-stack column in HBM is its global thread id.
 	extern __shared__ __attribute__((aligned(16))) int smem[];
 	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
-	int* spill = sv.spill + (blockIdx.x * BVH_BLOCK + threadIdx.x);
 	if (n_ptr) { int m = *n_ptr; n = m < n ? m : n; }  // count on the device, n = capacity (sync-free frame path)
 	uint32_t cn = 0, ct = 0, rays = 0;
 	grid_for_each(sv, n, [&](int64_t i) {
 		f3 O = ld3(org + 3 * (size_t)i), D = ld3(dir + 3 * (size_t)i);
 		Hit best;
 		uint32_t a = 0, b = 0;
-		bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, stack, BVH_BLOCK, spill, a, b);
+		bool any = bvh_trace<ANY, CENSUS>(sv, O, D, best, stack, BVH_BLOCK, a, b);
 		if (CENSUS && nv) { nv[i] = a; nt[i] = b; }
 		cn += a; ct += b; ++rays;
 		if (ANY) { if (occ) occ[i] = any ? 1 : 0; }

@@ -8,7 +8,7 @@
 // [lds_depth][block_threads] (so that every ds_read/ds_write of a wave touches 64 consecutive dwords
 // -> conflict free), `stride` = threads per block.  Only the first sv.lds_depth entries of a lane's
 // stack live in LDS (4 KB per wave at the default depth 16, so the full 32 waves/CU stay resident); deeper
-// entries -- rare -- go to `spill`, this thread's column of an HBM array [..][sv.spill_stride].
+// entries -- rare -- go to this thread's column (spill_column) of the HBM array sv.spill[..][sv.spill_stride].
 //   ANY = false: closest hit into `best` (prim = RT_MISS / t = +inf on a miss); returns hit?
 //   ANY = true : first accepted hit terminates; returns occluded?
 // The LDS part is addressed through an address_space(3) pointer so that push/pop are ds_write /
@@ -16,16 +16,20 @@
 typedef __attribute__((address_space(3))) int lds_int;
 #define RT_LDS_STACK(smem) ((lds_int*)(smem))
 
-__device__ __forceinline__ void stack_push(const SceneView& sv, lds_int* stack, int stride, int* spill, int sp, int v)
+// This thread's column of the overflow array, formed where it is needed (the rare path) instead of being carried
+// through the loop as a pointer: held to 64 VGPRs, k_shadow otherwise spills that pointer to scratch at entry.
+__device__ __forceinline__ size_t spill_column(int stride) { return (size_t)blockIdx.x * (size_t)stride + threadIdx.x; }
+
+__device__ __forceinline__ void stack_push(const SceneView& sv, lds_int* stack, int stride, int sp, int v)
 {
 	if (sp < sv.lds_depth) stack[sp * stride] = v;
-	else spill[(size_t)(sp - sv.lds_depth) * sv.spill_stride] = v;
+	else sv.spill[(size_t)(sp - sv.lds_depth) * sv.spill_stride + spill_column(stride)] = v;
 }
-__device__ __forceinline__ int stack_pop(const SceneView& sv, const lds_int* stack, int stride, const int* spill, int sp)
+__device__ __forceinline__ int stack_pop(const SceneView& sv, const lds_int* stack, int stride, int sp)
 {
 	int v;
 	if (sp < sv.lds_depth) v = stack[sp * stride];
-	else v = spill[(size_t)(sp - sv.lds_depth) * sv.spill_stride];
+	else v = sv.spill[(size_t)(sp - sv.lds_depth) * sv.spill_stride + spill_column(stride)];
 	return v;
 }
 
@@ -60,7 +64,7 @@ __device__ __forceinline__ void grid_for_each(const SceneView& sv, int64_t total
 
 template <bool ANY, bool CENSUS>
 __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& best, lds_int* stack, int stride,
-                                          int* spill, uint32_t& cnt_nodes, uint32_t& cnt_tris)
+                                          uint32_t& cnt_nodes, uint32_t& cnt_tris)
 {
 	best.prim = RT_MISS;
 	best.t = sv.tp.t_max;
@@ -89,7 +93,7 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 				slab2(rp, w0, w1, ANY ? sv.tp.t_max : best.t, hl, hr, tl, tr);
 				const bool right_first = hr && (!hl || tr < tl);
 				if (hl && hr) {
-					stack_push(sv, stack, stride, spill, sp, right_first ? ch.x : ch.y);
+					stack_push(sv, stack, stride, sp, right_first ? ch.x : ch.y);
 					++sp;
 				}
 				cur = right_first ? ch.y : ch.x;
@@ -111,7 +115,7 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 			}
 			if (pop) {
 				if (sp == 0) cur = EXIT;
-				else { --sp; cur = stack_pop(sv, stack, stride, spill, sp); }
+				else { --sp; cur = stack_pop(sv, stack, stride, sp); }
 			}
 		}
 	}
@@ -158,11 +162,10 @@ __device__ __forceinline__ bool brute_trace(const SceneView& sv, f3 O, f3 D, Hit
 }
 
 template <bool ANY>
-__device__ __forceinline__ bool scene_trace(const SceneView& sv, f3 O, f3 D, Hit& best, lds_int* stack, int stride,
-                                            int* spill)
+__device__ __forceinline__ bool scene_trace(const SceneView& sv, f3 O, f3 D, Hit& best, lds_int* stack, int stride)
 {
 	uint32_t a = 0, b = 0;
-	if (sv.use_bvh) return bvh_trace<ANY, false>(sv, O, D, best, stack, stride, spill, a, b);
+	if (sv.use_bvh) return bvh_trace<ANY, false>(sv, O, D, best, stack, stride, a, b);
 	return brute_trace<ANY>(sv, O, D, best);
 }
 
