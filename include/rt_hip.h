@@ -15,6 +15,11 @@
  *
  * A context is externally synchronised: one caller thread at a time (the reference's
  * processRays is non-re-entrant, rt_raytracer.cpp:27-48).  Independent contexts are independent.
+ *
+ * Results do not depend on the acceleration structure: every builder returns what the exhaustive
+ * search over the triangles returns, bit for bit (exact ties in t go to the lower primitive id), for
+ * ray origins at any distance; beyond ~1000 scene extents the triangle test's own float rounding
+ * (the reference's Moeller-Trumbore, unchanged) is coarser than a triangle and decides such ties.
  */
 #ifndef RT_HIP_H
 #define RT_HIP_H
