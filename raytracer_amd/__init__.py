@@ -33,6 +33,7 @@ assert RAY_DTYPE.itemsize == 64 and MATERIAL_DTYPE.itemsize == 48 and LIGHT_DTYP
 MISS = 0xFFFFFFFF
 TRIANGLES, SPHERES = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH, ACCEL_PLOC, ACCEL_SAH = 0, 1, 2, 3, 4
+NOALLOC_MAX_TEXELS = 1 << 24   # RT_HIP_NOALLOC_MAX_TEXELS (include/rt_hip.h)
 
 
 class Config(C.Structure):
@@ -67,7 +68,7 @@ ABI_SYMBOLS = [
     "rt_hip_unpack_chunks_device", "rt_hip_set_texture", "rt_hip_set_frame_texcoords_device",
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
-    "rt_hip_trace_census_device",
+    "rt_hip_trace_census_device", "rt_hip_gbuffer_select_noalloc_device",
 ]
 
 
@@ -125,6 +126,7 @@ def load_library() -> C.CDLL:
     L.rt_hip_trace_any_device.argtypes = [P, P, P, C.c_int, P]
     L.rt_hip_trace_census_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
     L.rt_hip_gbuffer_select_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, c_int_p]
+    L.rt_hip_gbuffer_select_noalloc_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, c_int_p]
     L.rt_hip_render_gbuffer_device.argtypes = [P, C.c_float, C.c_int, C.c_int, P, P]
     L.rt_hip_render_gbuffer_uv_device.argtypes = [P, C.c_float, C.c_int, C.c_int, P, P, P]
     L.rt_hip_set_texture.argtypes = [P, C.c_int, P, C.c_int, C.c_int]
@@ -357,6 +359,13 @@ class RtHip:
         cnt = C.c_int(0)
         self._ck(self.lib.rt_hip_gbuffer_select_device(self.h, _dptr(d_nrm_rgba), _dptr(d_pos_rgb), n, interlace, phase,
                                                        _dptr(d_pos_out), _dptr(d_nrm_out), _dptr(d_index_out), C.byref(cnt)))
+        return cnt.value
+
+    def gbuffer_select_noalloc_device(self, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_pos_out, d_nrm_out, d_index_out):
+        """The allocation-free variant (fixed per-GPU scratch, n <= 2^24)."""
+        cnt = C.c_int(0)
+        self._ck(self.lib.rt_hip_gbuffer_select_noalloc_device(self.h, _dptr(d_nrm_rgba), _dptr(d_pos_rgb), n, interlace, phase,
+                                                               _dptr(d_pos_out), _dptr(d_nrm_out), _dptr(d_index_out), C.byref(cnt)))
         return cnt.value
 
     def render_gbuffer_device(self, fov, w, h, d_nrm_rgba, d_pos_rgb):

@@ -307,6 +307,7 @@ int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out)
 	if (ndev <= 0) { rt_set_error("no HIP device visible: librt_hip has no CPU fallback"); return RT_HIP_ERR_HIP; }
 	if (cfg->device < 0 || cfg->device >= ndev) { rt_set_error("device %d out of range (%d devices)", cfg->device, ndev); return RT_HIP_ERR_ARG; }
 	RT_HIP_CHECK(hipSetDevice(cfg->device));
+	RT_CHECK(rt_noalloc_setup(cfg->device));  // this GPU's address of the allocation-free entry's fixed scratch (k_noalloc.hip)
 	rt_hip_ctx* ctx = new rt_hip_ctx();
 	ctx->cfg = *cfg;
 	memset(&ctx->stats, 0, sizeof(ctx->stats));
@@ -694,6 +695,18 @@ int rt_hip_gbuffer_select_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const
 		return RT_HIP_ERR_ARG;
 	}
 	return rt_gbuffer_select(ctx, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_positions_out, d_normals_out, d_index_out, out_count);
+}
+
+int rt_hip_gbuffer_select_noalloc_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n, int interlace,
+                                         int phase, float* d_positions_out, float* d_normals_out, int* d_index_out,
+                                         int* out_count)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (n < 0 || !out_count || (n > 0 && (!d_nrm_rgba || !d_pos_rgb || !d_positions_out || !d_normals_out))) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	return rt_gbuffer_select_noalloc(ctx, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_positions_out, d_normals_out, d_index_out, out_count);
 }
 
 int rt_hip_render_gbuffer_device(rt_hip_ctx* ctx, float fov, int width, int height, float* d_nrm_rgba, float* d_pos_rgb)
