@@ -5,28 +5,37 @@
 
 Workload (config.workload): "atrium-262k-1080p" = BASELINE.json configs[2], the configuration the
 metric ("secondary Mrays/s + ms/frame @1080p, 1/2/4/8 MI355X") is quoted on: a ~262k-triangle
-procedural atrium (real Sponza cannot be fetched offline), GPU LBVH, 1080p G-buffer resident in
+procedural atrium (real Sponza cannot be fetched offline), GPU-built BVH, 1080p G-buffer resident in
 HBM, Gen-1 shading with shadow + reflection + refraction rays, 2 bounces.
 
-A step = one frame's worth of texels per GPU.  At N GPUs the job renders N frames (N fields of
-view) per step and every frame is split over the ranks by interleaved 64x64 tiles, so each rank
-traces one frame's worth of texels (weak scaling: per-GPU work is fixed) -- its tiles of all N
-frames as one batch, so the launches stay frame-sized.  The scene and the LBVH
-are replicated; the only collective is the gather of the finished tiles, inside the timed region: every
-rank packs its tiles of frame f, one RCCL all-to-all sends them to rank f, which assembles frame f
-(raytracer_amd/frames.py), so only owned pixels travel.
+A step = `config.frames_per_step` frames, so that the timed region lasts about a second and the
+driver's own GPU-busy sampling can see it.  Two ways to use N GPUs:
+  --scaling weak (default)  every sub-step renders N frames (N fields of view); each frame is split over
+        the ranks by interleaved 64x64 tiles, so a rank traces one frame's worth of texels (its tiles of
+        all N frames in ONE wavefront); one all-to-all per sub-step sends rank r's tiles of frame f to
+        rank f, overlapped with the next sub-step's kernels.  Per-GPU work is fixed.
+  --scaling strong          every sub-step renders ONE frame split over the N ranks; the finished tiles
+        are all-gathered (RCCL) and every rank assembles the whole frame before the next one starts,
+        so ms_per_frame is the latency of a frame.  Total work is fixed.
+config.ms_per_frame is always wall time / frames completed by the whole job (1 / throughput);
+config.frame_latency_ms is the time from a frame's first kernel to its assembled image.
 
-value = secondary rays issued by all ranks / wall time (barrier + synchronize on both sides, max
-over ranks).  roofline = the dominant kernel (the shadow any-hit traversal k_shadow) against HBM:
-algorithmic bytes = rays x (32 B x nodes/ray + 48 B x tris/ray + 48 B ray in/out), with nodes/ray
-and tris/ray counted on the device by a census pass over the identical frame.  cpu_baseline = the
-compiled reference's own RayTracer::processRays (oracle/_ref, kind "reference") or the oracle's
-restatement (kind "port") on a bounded sample of the same G-buffer, single thread as the
-reference is.
+value = secondary rays issued by all ranks / wall time (barrier + synchronize on both sides, max over
+ranks), inputs resident in HBM.  roofline = the kernel with the most GPU time among ALL timed kernels
+of the frame (the fused shadow / closest-hit traversal k_shadow; with --photons the photon gather),
+priced against the resource the counters show it is bound by -- the vector ALU -- with frac <= 1:
+algorithmic FLOP (34 per BVH node visit, 45 per triangle test, counted on the device by a census pass
+over the identical frame) / launch time against the 157.3 TFLOP/s FP32 vector peak; the HBM side
+(counter bytes per launch, offline rocprofv3 passes of this same command under profiles/) is reported
+beside it.  cpu_baseline = the compiled reference's own RayTracer::processRays (oracle/_ref, kind
+"reference") or the oracle's restatement (kind "port") on a bounded sample of the same G-buffer,
+single thread as the reference is.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -37,21 +46,46 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-NODE_FLOP, TRI_FLOP = 34.0, 45.0   # per node visit: 12 FMA (24) + 8 min/max + 2 compares; per triangle test: Moeller-Trumbore up to t
-NODE_BYTES = 32.0  # the traversal reads 32-byte quantised nodes (rt_dev.h: QNode); SURVEY 8d prices the float node at 64
-VALU_PEAK_TFLOPS = 78.6  # per-lane v_fma_f32 rate (157 TFLOP/s needs packed/dual-issue FP32 throughout)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 vector peak (packed / dual-issue FMA on every lane)
+VALU_UNPACKED_TFLOPS = 78.6      # plain per-lane v_fma_f32: what scalar-per-lane ray code can issue
+NODE_FLOP, TRI_FLOP = 34.0, 45.0  # per node visit: 12 FMA (24) + 8 min/max + 2 compares for both child boxes; per triangle test: Moeller-Trumbore up to t
+NODE_BYTES = 32.0                # the traversal reads 32-byte quantised nodes (rt_dev.h: QNode)
+NODE_BYTES_SURVEY = 64.0         # SURVEY.md 8d prices a node visit at the 64-byte float node
+GATHER_VISIT_FLOP = 10.0         # per photon visited: 3 sub + 5 (dot) + compare + count/max
+GATHER_VISIT_BYTES = 16.0        # position record
 
 
-def pmc_traffic(workload, shadow_mode, accel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes of this
-    same command (profiles/r1_pmc_traffic.json, made by scripts/profile_round.sh); None for any other
-    configuration -- counters cannot be read from inside the process being measured."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if not (workload == "atrium-262k-1080p" and shadow_mode == "corrected" and accel == "ploc" and os.path.exists(path)):
-        return None
-    with open(path) as f:
-        return float(json.load(f)["traffic_bytes_per_launch"])
+def kernel_source_hash():
+    """Identity of the kernels a counter profile was taken with: sha256 over the sources of the traversal, frame and
+    gather kernels and their build flags."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for name in ("Makefile", "k_frame.hip", "k_photon.hip", "k_trace.hip", "rt_dev.h", "rt_trace_dev.h"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def offline_counters(workload, shadow_mode, accel, photons):
+    """The rocprofv3 --pmc passes of this same command (scripts/profile_round.sh writes the summary; counters
+    cannot be read from inside the process being measured).  Returned only when the profile was taken on the
+    same workload, builder and kernel sources; otherwise (None, why)."""
+    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            c = json.load(f)
+        want = dict(workload=workload + ("+photons" if photons else ""), shadows=shadow_mode, accel=accel)
+        have = dict(workload=c.get("workload"), shadows=c.get("shadows", "corrected"), accel=c.get("accel", "ploc"))
+        if want != have:
+            return None, "profiles/%s is for %s, this run is %s" % (name, have, want)
+        if c.get("kernel_source_hash") != kernel_source_hash():
+            return None, "profiles/%s was taken with other kernel sources (%s, now %s)" % (name, c.get("kernel_source_hash"), kernel_source_hash())
+        c["file"] = "profiles/" + name
+        return c, "offline: rocprofv3 --pmc passes of this command, same workload / builder / kernel sources (%s)" % c["file"]
+    return None, "no counter profile committed"
 
 
 def parse_args():
@@ -59,6 +93,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-step", type=int, default=0,
+                    help="sub-steps per step (0 = auto: 50, or 2 with --photons): sized so that the timed region lasts ~1 s")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--workload", default="atrium-262k-1080p",
                     choices=["atrium-262k-1080p", "atrium-1m-1080p", "atrium-1m-4k", "cornell-1080p", "atrium-8k-small"])
     ap.add_argument("--shadow-mode", default="corrected", choices=["corrected", "literal"],
@@ -72,6 +109,8 @@ def parse_args():
                     help="N = 1 only: frames in flight = contexts (each its own stream) fed from as many host threads; the "
                          "default 1 keeps the kernels of a frame alone on the GPU, which is what the roofline object measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra figures (host-to-host and with-rebuild ms/frame, literal shadows, the 1M-triangle target config)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="G-buffer texels fed to the CPU baseline (0 = auto)")
     return ap.parse_args()
 
@@ -83,6 +122,23 @@ WORKLOADS = {
     "cornell-1080p": dict(tris=0, w=1920, h=1080),
     "atrium-8k-small": dict(tris=8192, w=480, h=270),
 }
+
+
+def timed_frames(g, gb_p, gb_n, W, H, out, frames, warm=3):
+    """ms per frame of `frames` device-resident whole frames on context g (after `warm` untimed ones)."""
+    import torch
+    render = type(g).render_tiles_batch_device.__wrapped__
+    rays = 0
+    for _ in range(warm):
+        render(g, [gb_p], [gb_n], W, H, 64, 0, 1, [out])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        render(g, [gb_p], [gb_n], W, H, 64, 0, 1, [out])
+        rays += g.last_frame_rays()
+    g.sync()
+    dt = time.perf_counter() - t0
+    return dt / frames * 1e3, rays / dt / 1e6, rays // frames
 
 
 def main():
@@ -135,8 +191,11 @@ def main():
         photon_info = {"photons_per_light": args.photons, "photons_stored": nph,
                        "photon_pass_ms": round((time.perf_counter() - t0) * 1e3, 3)}
 
-    # ---- inputs resident in HBM: one G-buffer per frame of the step -------------------------
-    nframes = world
+    strong = args.scaling == "strong" and world > 1
+    K = args.frames_per_step if args.frames_per_step > 0 else (2 if args.photons > 0 else 50)
+
+    # ---- inputs resident in HBM: one G-buffer per frame of a sub-step -------------------------
+    nframes = 1 if strong else world
     npix = W * H
     gb_n, gb_p = [], []
     for f in range(nframes):
@@ -151,31 +210,36 @@ def main():
         print("rank %d: build %s, covered texels per frame %s" % (rank, {k: build_stats[k] for k in ("num_tris", "num_nodes", "bvh_depth", "build_ms")}, cov),
               file=sys.stderr, flush=True)
     tiles = [torch.zeros(npix * 4, dtype=torch.uint8, device=dev) for _ in range(nframes)]   # this rank's tiles of each frame
-    frame = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)    # N > 1: frame `rank`, assembled from all ranks' tiles
+    frame = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)    # N > 1: the frame assembled from all ranks' tiles
     xchg = None
     if world > 1:
-        from raytracer_amd.frames import TileExchange
-        xchg = TileExchange(g, W, H, 64, rank, world, dev)
+        from raytracer_amd.frames import TileExchange, TileAllGather
+        xchg = TileAllGather(g, W, H, 64, rank, world, dev) if strong else TileExchange(g, W, H, 64, rank, world, dev)
 
     render_batch = rt.RtHip.render_tiles_batch_device.__wrapped__
 
-    def step():
-        # this rank's tiles of all the step's frames in one wavefront (a batch of one at N = 1)
-        if xchg and os.environ.get("BENCH_XCHG") == "pack":   # debugging aid: full-size tile images, then pack kernels
+    def substep():
+        # this rank's tiles of all the sub-step's frames in one wavefront (a batch of one at N = 1)
+        if strong:
+            xchg.render(gb_p[0], gb_n[0])     # this rank's tiles of THE frame, packed
+            rays = g.last_frame_rays()
+            xchg.gather(frame)                # RCCL all-gather of the chunks + unpack: every rank holds the whole frame
+            g.sync()                          # ... before the next frame starts: a frame's latency, not a pipeline's rate
+        elif xchg and os.environ.get("BENCH_XCHG") == "pack":   # debugging aid: full-size tile images, then pack kernels
             g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
             rays = g.last_frame_rays()
             for f in range(nframes):
                 xchg.pack(f, tiles[f])
             xchg.exchange(frame)
-        elif xchg and os.environ.get("BENCH_XCHG") == "sync":   # collective between the steps instead of under the next one
+        elif xchg and os.environ.get("BENCH_XCHG") == "sync":   # collective between the sub-steps instead of under the next one
             xchg.render(gb_p, gb_n)
             rays = g.last_frame_rays()
             xchg.exchange(frame)
         elif xchg:
             xchg.render(gb_p, gb_n)       # ... written straight into the packed chunks: chunk f goes to rank f
             rays = g.last_frame_rays()
-            xchg.finish(frame)            # the PREVIOUS step's all-to-all ran under this step's kernels: unpack -> its frame `rank` is complete
-            xchg.begin()                  # this step's all-to-all (RCCL, own stream); finished during the next step, or by drain()
+            xchg.finish(frame)            # the PREVIOUS sub-step's all-to-all ran under this one's kernels: unpack -> its frame `rank` is complete
+            xchg.begin()                  # this sub-step's all-to-all (RCCL, own stream); finished during the next one, or by drain()
         else:
             # the binding's un-fenced entry: the G-buffers were complete before the loop and the call itself
             # returns only after its last kernel, so the per-call torch-stream drain has nothing to wait for
@@ -183,9 +247,12 @@ def main():
             rays = g.last_frame_rays()
         return rays
 
+    def step():
+        return sum(substep() for _ in range(K))
+
     def drain():
-        if xchg:
-            xchg.finish(frame)            # the last step's exchange belongs to the timed region
+        if xchg and not strong:
+            xchg.finish(frame)            # the last sub-step's exchange belongs to the timed region
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -194,7 +261,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     # --inflight M: M - 1 further contexts (scene and BVH replicated, own stream, own output), one host thread each;
-    # step k goes to context k % M.  The frames overlap on the GPU: the tail of one frame's kernels and the host's
+    # sub-step k goes to context k % M.  The frames overlap on the GPU: the tail of one frame's kernels and the host's
     # per-frame work disappear under the other frame's kernels.
     inflight = max(1, args.inflight) if world == 1 and args.photons == 0 else 1
     extra = []
@@ -211,7 +278,7 @@ def main():
 
         def worker(t):
             ctx, out = (g, tiles) if t == 0 else extra[t - 1]
-            for _ in range(t, count, inflight):
+            for _ in range(t, count * K, inflight):
                 render_batch(ctx, gb_p, gb_n, W, H, 64, rank, world, out)
                 rays[t] += ctx.last_frame_rays()
         th = [threading.Thread(target=worker, args=(t,)) for t in range(inflight)]
@@ -242,100 +309,264 @@ def main():
         dist.all_reduce(ry, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     total_rays = float(ry.item())
+    substeps = args.steps * K
+    frames_done = substeps * nframes
 
     # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------
-    any_ms, any_launches, rays_any = st["any_ms"], st["any_launches"], st["rays_any"]
-    clo_ms, clo_launches, rays_clo = st["closest_ms"], st["closest_launches"], st["rays_closest"]
-    # census pass: same frame(s), counting node visits / triangle tests per ray (untimed)
-    g.set_config(census=1, profile=0)
-    g.reset_stats()
-    g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
-    cs = g.stats()
-    g.set_config(census=0, profile=1)
-    nodes_any = cs["census_nodes_any"] / max(cs["census_rays_any"], 1)
-    tris_any = cs["census_tris_any"] / max(cs["census_rays_any"], 1)
-    nodes_clo = cs["census_nodes_closest"] / max(cs["census_rays_closest"], 1)
-    tris_clo = cs["census_tris_closest"] / max(cs["census_rays_closest"], 1)
-    bytes_per_any = NODE_BYTES * nodes_any + 48.0 * tris_any + 48.0
-    bytes_per_clo = NODE_BYTES * nodes_clo + 48.0 * tris_clo + 48.0
-    fused = clo_launches == 0 and rays_clo > 0   # the frame driver folds the closest-hit queues into the shadow launches
-    if fused:
-        dominant = "k_shadow (shadow any-hit rays + the level's closest-hit queue in the same launch)"
-        launches = max(any_launches, 1)
-        rays_per_launch = (rays_any + rays_clo) / launches
-        avg_ms = any_ms / launches
-        bytes_per_launch = (rays_any * bytes_per_any + rays_clo * bytes_per_clo) / launches
-        bpr = bytes_per_launch / max(rays_per_launch, 1)
-        nodes_dom = (rays_any * nodes_any + rays_clo * nodes_clo) / max(rays_any + rays_clo, 1)
-        tris_dom = (rays_any * tris_any + rays_clo * tris_clo) / max(rays_any + rays_clo, 1)
-    elif any_ms >= clo_ms:
-        dominant = "k_shadow (any-hit)"
-        rays_per_launch = rays_any / max(any_launches, 1)
-        avg_ms = any_ms / max(any_launches, 1)
-        bpr, nodes_dom, tris_dom = bytes_per_any, nodes_any, tris_any
-    else:
-        dominant = "k_bvh (closest-hit)"
-        rays_per_launch = rays_clo / max(clo_launches, 1)
-        avg_ms = clo_ms / max(clo_launches, 1)
-        bpr, nodes_dom, tris_dom = bytes_per_clo, nodes_clo, tris_clo
-    achieved = (rays_per_launch * bpr) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(args.workload, args.shadow_mode, args.accel) if (world == 1 and args.photons == 0) else None,
-                "traffic_note": "HBM-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_traffic.json); the "
-                                "algorithmic bytes are served by L1/L2/Infinity Cache, so achieved > peak is expected and HBM "
-                                "is not the binding limit: see `valu`",
-                "valu": {"unit": "TFLOP/s", "flop_per_ray": round(NODE_FLOP * nodes_dom + TRI_FLOP * tris_dom, 1),
-                         "achieved": round(rays_per_launch * (NODE_FLOP * nodes_dom + TRI_FLOP * tris_dom) / (avg_ms * 1e-3) / 1e12, 2) if avg_ms > 0 else 0.0,
-                         "peak": VALU_PEAK_TFLOPS,
-                         "frac": round(rays_per_launch * (NODE_FLOP * nodes_dom + TRI_FLOP * tris_dom) / (avg_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4) if avg_ms > 0 else 0.0},
-                "kernel": dominant, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": round(rays_per_launch, 1),
-                "nodes_per_ray": round(nodes_dom, 2), "tris_per_ray": round(tris_dom, 2),
-                "bytes_per_ray": round(bpr, 1),
-                "kernel_mrays_per_s": round(rays_per_launch / (avg_ms * 1e-3) / 1e6, 1) if avg_ms > 0 else 0.0,
-                "any_hit": {"rays_per_frame": round(rays_any / max(st["frames"], 1), 1), "nodes_per_ray": round(nodes_any, 2),
-                            "tris_per_ray": round(tris_any, 2)},
-                "closest": {"rays_per_frame": round(rays_clo / max(st["frames"], 1), 1), "nodes_per_ray": round(nodes_clo, 2),
-                            "tris_per_ray": round(tris_clo, 2), "standalone_launches": clo_launches,
-                            "avg_launch_ms": round(clo_ms / max(clo_launches, 1), 4)}}
+    roofline = build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong)
 
-    # ---- CPU baseline on rank 0 (N = 1 only) ------------------------------------------------
     # ---- N > 1 (untimed): the frame assembled from all ranks' tiles == the same frame shaded whole on this rank ----
     tiles_verified = None
     if xchg:
         whole = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)
-        g.render_frame_device(gb_p[rank], gb_n[rank], W, H, whole)
+        g.render_frame_device(gb_p[0 if strong else rank], gb_n[0 if strong else rank], W, H, whole)
         ok = torch.tensor([1.0 if torch.equal(whole, frame) else 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         tiles_verified = bool(ok.item() == 1.0)
+
+    # ---- untimed extras on rank 0 at N = 1: the spans SURVEY 8d defines around the device-resident frame ----
+    extras, target = {}, None
+    if rank == 0 and world == 1 and not args.no_extras and args.photons == 0 and inflight == 1:
+        extras, target = run_extras(args, rt, scenes, g, scene, gb_p[0], gb_n[0], W, H, dev, dev_index, ACCEL)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(scene, gb_n[0], gb_p[0], W, H, args.cpu_sample)
 
     if rank == 0:
+        ms_per_frame = elapsed / frames_done * 1e3
+        latency = elapsed / substeps * 1e3
         out = {
             "metric": "secondary Mrays/s", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload + ("+photons" if args.photons > 0 else ""), "scene": scene.name, "triangles": scene.num_tris, "width": W, "height": H,
-                       "frames_per_step": nframes, "tile": 64, "bounces": 2, "lights": len(scene.lights),
+                       "frames_per_step": K * nframes, "tile": 64, "bounces": 2, "lights": len(scene.lights),
                        "shadows": args.shadow_mode, "accel": args.accel, "parallelism": "tiles x%d" % world,
                        **({"frames_in_flight": inflight} if inflight > 1 else {}),
-                       "rays_per_frame": round(total_rays / args.steps / nframes, 1),
-                       "ms_per_frame": round(elapsed / args.steps * 1e3, 3),
+                       "rays_per_frame": round(total_rays / frames_done, 1),
+                       "ms_per_frame": round(ms_per_frame, 4),
+                       "frame_latency_ms": round(latency, 4),
+                       "ms_per_frame_definition": "ms_per_frame = wall time / frames completed by the whole job (G-buffer and image resident in "
+                                                  "HBM, BVH build excluded); frame_latency_ms = first kernel to assembled image of one frame"
+                                                  + (" (= one frame split over all ranks + all-gather of its tiles)" if strong else
+                                                     " (at N > 1: of the N frames of one sub-step, rendered together)" if world > 1 else ""),
+                       "timed_region_s": round(elapsed, 3),
                        "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"],
-                       **({"exchange": "all-to-all of packed tiles, overlapped with the next step" if os.environ.get("BENCH_XCHG") is None else os.environ["BENCH_XCHG"],
+                       **extras,
+                       **({"exchange": ("all-gather of packed tiles after every frame" if strong else
+                                        "all-to-all of packed tiles, overlapped with the next sub-step") if os.environ.get("BENCH_XCHG") is None else os.environ["BENCH_XCHG"],
                            "assembled_frames_equal_whole_frames": tiles_verified} if xchg else {}),
                        **({"photon_map": photon_info} if photon_info else {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
+        if target:
+            out["target_config"] = target
         print(json.dumps(out))
     g.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
+    """One flat object for the kernel with the most GPU time among all timed kernels of the frame."""
+    any_ms, any_launches, rays_any = st["any_ms"], st["any_launches"], st["rays_any"]
+    clo_ms, clo_launches, rays_clo = st["closest_ms"], st["closest_launches"], st["rays_closest"]
+    gat_ms, gat_launches, gat_points = st["gather_ms"], st["gather_launches"], st["gather_points"]
+    frame_ms = st["frame_ms"]
+    # census pass: same frame(s), counting node visits / triangle tests per ray and photons per gather (untimed)
+    g.set_config(census=1, profile=0)
+    g.reset_stats()
+    if strong:
+        g.render_tiles_device(gb_p[0], gb_n[0], W, H, 64, rank, world, tiles[0])
+    else:
+        g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
+    cs = g.stats()
+    g.set_config(census=0, profile=1)
+    nodes_any = cs["census_nodes_any"] / max(cs["census_rays_any"], 1)
+    tris_any = cs["census_tris_any"] / max(cs["census_rays_any"], 1)
+    nodes_clo = cs["census_nodes_closest"] / max(cs["census_rays_closest"], 1)
+    tris_clo = cs["census_tris_closest"] / max(cs["census_rays_closest"], 1)
+    counters, counters_note = offline_counters(args.workload, args.shadow_mode, args.accel, args.photons > 0) if world == 1 else (None, "N > 1: no counter profile")
+
+    share = lambda ms: round(ms / frame_ms, 4) if frame_ms > 0 else None
+    if gat_ms > max(any_ms, clo_ms):
+        # photon-mapped frames: radiance_estimate's gather (k_photon_gather + k_photon_gather_wave, timed as one)
+        launches = max(gat_launches, 1)
+        avg_ms = gat_ms / launches
+        visits = cs["census_gather_visits"] / max(cs["gather_launches"], 1)     # photons in the cubes of one launch's points
+        points = gat_points / launches
+        flops = visits * GATHER_VISIT_FLOP
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
+                "traffic": counters.get("traffic_bytes_per_launch") if counters else None,
+                "kernel": "k_photon_gather + k_photon_gather_wave (radiance_estimate: one lane per point, one wave per point with > 1024 photons in its cube)",
+                "avg_launch_ms": round(avg_ms, 4), "share_of_frame_gpu_time": share(gat_ms),
+                "points_per_launch": round(points, 1), "photon_visits_per_launch": round(visits, 1),
+                "photon_visits_per_point": round(visits / max(points, 1), 1),
+                "flop_per_visit": GATHER_VISIT_FLOP, "bytes_per_visit": GATHER_VISIT_BYTES,
+                "work_definition": "the mandatory first pass only: every photon of the grid cells within the radius is read once (16 B) "
+                                   "to count the candidates and find max_dist2 (rt_photon_map.cpp:159-169); the selection passes are not credited",
+                "frac_unpacked_peak": round(achieved / VALU_UNPACKED_TFLOPS, 4), "peak_unpacked": VALU_UNPACKED_TFLOPS,
+                "algorithmic_cache_GBs": round(visits * GATHER_VISIT_BYTES / (avg_ms * 1e-3) / 1e9, 1),
+                "algorithmic_cache_note": "16 B x photon visits / launch time: served by L1/L2 (neighbouring points read the same cells), not an HBM rate",
+                "bound_note": "vector-ALU issue: the pass is a distance test per photon out of cache-resident cells; the selection passes and "
+                              "the load imbalance between points are why the credited first pass reaches a small fraction of the peak"}
+    else:
+        fused = clo_launches == 0 and rays_clo > 0   # the frame driver folds the closest-hit queues into the shadow launches
+        if fused:
+            dominant = "k_shadow (shadow any-hit rays + the level's closest-hit queue in the same launch)"
+            launches = max(any_launches, 1)
+            rays_per_launch = (rays_any + rays_clo) / launches
+            avg_ms, kernel_ms = any_ms / launches, any_ms
+            nodes_dom = (rays_any * nodes_any + rays_clo * nodes_clo) / max(rays_any + rays_clo, 1)
+            tris_dom = (rays_any * tris_any + rays_clo * tris_clo) / max(rays_any + rays_clo, 1)
+        elif any_ms >= clo_ms:
+            dominant = "k_shadow (any-hit)"
+            rays_per_launch = rays_any / max(any_launches, 1)
+            avg_ms, kernel_ms = any_ms / max(any_launches, 1), any_ms
+            nodes_dom, tris_dom = nodes_any, tris_any
+        else:
+            dominant = "k_bvh (closest-hit)"
+            rays_per_launch = rays_clo / max(clo_launches, 1)
+            avg_ms, kernel_ms = clo_ms / max(clo_launches, 1), clo_ms
+            nodes_dom, tris_dom = nodes_clo, tris_clo
+        flop_per_ray = NODE_FLOP * nodes_dom + TRI_FLOP * tris_dom
+        sec = avg_ms * 1e-3
+        achieved = rays_per_launch * flop_per_ray / sec / 1e12 if avg_ms > 0 else 0.0
+        bpr32 = NODE_BYTES * nodes_dom + 48.0 * tris_dom + 48.0
+        bpr64 = NODE_BYTES_SURVEY * nodes_dom + 48.0 * tris_dom + 48.0
+        roof = {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
+                "traffic": counters.get("traffic_bytes_per_launch") if counters else None,
+                "kernel": dominant, "avg_launch_ms": round(avg_ms, 4), "share_of_frame_gpu_time": share(kernel_ms),
+                "rays_per_launch": round(rays_per_launch, 1), "flop_per_ray": round(flop_per_ray, 1),
+                "nodes_per_ray": round(nodes_dom, 2), "tris_per_ray": round(tris_dom, 2),
+                "kernel_mrays_per_s": round(rays_per_launch / sec / 1e6, 1) if avg_ms > 0 else 0.0,
+                "work_definition": "34 FLOP per BVH node visit (both child boxes: 12 FMA + 8 min/max + 2 compares) + 45 per triangle test "
+                                   "(SURVEY.md 8d), visits and tests counted on the device by a census pass over the identical frame",
+                "frac_unpacked_peak": round(achieved / VALU_UNPACKED_TFLOPS, 4), "peak_unpacked": VALU_UNPACKED_TFLOPS,
+                "algorithmic_cache_GBs_32B_nodes": round(rays_per_launch * bpr32 / sec / 1e9, 1) if avg_ms > 0 else 0.0,
+                "algorithmic_cache_GBs_64B_nodes": round(rays_per_launch * bpr64 / sec / 1e9, 1) if avg_ms > 0 else 0.0,
+                "algorithmic_cache_note": "rays x (node bytes x nodes/ray + 48 x tris/ray + 48): the 32-byte quantised node the kernel reads, and "
+                                          "SURVEY 8d's 64-byte price; served by L1/L2/Infinity Cache (re-reads of a ~21 MB tree), NOT an HBM rate "
+                                          "-- the HBM side is hbm_counter_GBs",
+                "any_hit_rays_per_frame": round(rays_any / max(st["frames"], 1), 1), "any_hit_nodes_per_ray": round(nodes_any, 2),
+                "any_hit_tris_per_ray": round(tris_any, 2),
+                "closest_rays_per_frame": round(rays_clo / max(st["frames"], 1), 1), "closest_nodes_per_ray": round(nodes_clo, 2),
+                "closest_tris_per_ray": round(tris_clo, 2), "closest_standalone_launches": clo_launches}
+    avg_ms = roof["avg_launch_ms"]
+    if counters:
+        t = counters.get("traffic_bytes_per_launch")
+        if t and avg_ms > 0:
+            roof["hbm_counter_GBs"] = round(t / (avg_ms * 1e-3) / 1e9, 1)
+            roof["hbm_frac"] = round(t / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        for k in ("valu_issue_frac", "lanes_active_frac", "ta_busy_frac", "td_busy_frac", "l1_hit_frac", "l2_hit_frac", "profiled_avg_launch_ms"):
+            if k in counters:
+                roof[k] = counters[k]
+    roof["counters_source"] = counters_note
+    roof.setdefault("bound_note", "per the counters the kernel is limited by vector-ALU issue together with the vector-memory pipeline (TA/TD), at "
+                                  "two thirds of the lanes active; HBM carries a few percent of its peak")
+    return roof
+
+
+def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACCEL):
+    """Figures SURVEY 8d asks for beside the device-resident frame, none of them `value`: the host-to-host frame
+    (G-buffer uploaded with hipMemcpyAsync from pinned memory -> image in pinned host memory), the frame with the
+    acceleration structure brought up to date first (what RayTracer::processRays does every call,
+    rt_raytracer.cpp:457-503), the literal-shadow mode, and the north_star target scene (~1M triangles, 1080p)."""
+    import torch
+    npix = W * H
+    out_dev = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)
+    cfg = {}
+    # host-to-host through rt_hip_render_frame (pinned host buffers)
+    h_p = gb_p.cpu().pin_memory()
+    h_n = gb_n.cpu().pin_memory()
+    h_o = torch.zeros(npix * 4, dtype=torch.uint8).pin_memory()
+    fp = ctypes.POINTER(ctypes.c_float)
+    call = lambda: g._ck(g.lib.rt_hip_render_frame(g.h, ctypes.cast(h_p.data_ptr(), fp), ctypes.cast(h_n.data_ptr(), fp), W, H,
+                                                   ctypes.cast(h_o.data_ptr(), ctypes.POINTER(ctypes.c_uint8))))
+    for _ in range(3):
+        call()
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        call()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    cfg["ms_per_frame_host_to_host"] = round(float(np.median(ts)), 3)
+    cfg["host_to_host_note"] = ("rt_hip_render_frame: %.1f MB G-buffer up with hipMemcpyAsync from pinned host memory, frame, %.1f MB image down; "
+                                "median of 20; PCIe-bound, never `value`" % (npix * 28 / 1e6, npix * 4 / 1e6))
+    # the frame with the scene brought up to date first
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    moved = ident.copy()
+    render = type(g).render_tiles_batch_device.__wrapped__
+
+    def frame_after(prepare, n=20):
+        ts = []
+        for i in range(n + 3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            prepare(i)
+            g.update()
+            render(g, [gb_p], [gb_n], W, H, 64, 0, 1, [out_dev])
+            g.sync()
+            if i >= 3:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        return round(float(np.median(ts)), 3)
+
+    nm = len(scene.meshes)
+    mats = [np.ascontiguousarray(me.model_colmajor(), dtype=np.float32).reshape(16) for me in scene.meshes]
+
+    def same(i):
+        for m in range(nm):
+            g.set_model_mat(m, mats[m])
+
+    def jitter(i):   # every mesh moved a little and back: new boxes, same topology
+        for m in range(nm):
+            mm = mats[m].copy()
+            mm[12] += 1e-3 * (1 + (i & 1))
+            g.set_model_mat(m, mm)
+
+    cfg["ms_per_frame_with_update_unchanged"] = frame_after(same)
+    cfg["ms_per_frame_with_update_moved"] = frame_after(jitter)
+    same(0)
+    if hasattr(g, "force_rebuild"):
+        cfg["ms_per_frame_with_rebuild"] = frame_after(lambda i: g.force_rebuild())
+    else:
+        cfg["ms_per_frame_with_rebuild"] = cfg["ms_per_frame_with_update_moved"]
+    same(0)
+    g.update()
+    cfg["with_update_note"] = ("set every Mesh::model_mat + rt_hip_update + the device-resident frame, median of 20 (what processRays' per-call soup "
+                               "rebuild, rt_raytracer.cpp:457-503, costs here): unchanged matrices, matrices moved, full rebuild forced")
+    # literal reference shadows on the same frame
+    if args.shadow_mode == "corrected":
+        g.set_config(shadow_t_max=0.0)
+        ms, mr, rpf = timed_frames(g, gb_p, gb_n, W, H, out_dev, 100)
+        g.set_config(shadow_t_max=1.0)
+        cfg["literal_shadows_ms_per_frame"] = round(ms, 4)
+        cfg["literal_shadows_mrays_per_s"] = round(mr, 1)
+    # north_star's target: ~1M triangles at 1080p, same shading
+    target = None
+    if args.workload == "atrium-262k-1080p":
+        sc1 = scenes.atrium(1048576)
+        g1 = rt.RtHip(sc1, semantics="array", accel=ACCEL[args.accel], device=dev_index, profile=0, bounces=2, do_shadows=1,
+                      shadow_t_max=1.0 if args.shadow_mode == "corrected" else 0.0, seed=42)
+        b1 = g1.stats()
+        d_n = torch.zeros(npix * 4, dtype=torch.float32, device=dev)
+        d_p = torch.zeros(npix * 3, dtype=torch.float32, device=dev)
+        g1.render_gbuffer_device(sc1.fov, W, H, d_n, d_p)
+        g1.sync()
+        ms, mr, rpf = timed_frames(g1, d_p, d_n, W, H, out_dev, 200)
+        target = {"workload": "atrium-1m-1080p", "scene": sc1.name, "triangles": sc1.num_tris, "width": W, "height": H,
+                  "value": round(mr, 2), "unit": "Mrays/s", "ms_per_frame": round(ms, 4), "frames": 200, "rays_per_frame": int(rpf),
+                  "shadows": args.shadow_mode, "accel": args.accel, "bvh_build_ms": round(b1["build_ms"], 3), "bvh_depth": b1["bvh_depth"],
+                  "note": "north_star's target scene size (~1M triangles, 1080p), same run, G-buffer and image resident in HBM, 1 GPU"}
+        g1.close()
+    return cfg, target
 
 
 def run_cpu_baseline(scene, d_n, d_p, W, H, sample):

@@ -143,6 +143,10 @@ typedef struct rt_hip_stats {
 	int64_t frames;
 	uint64_t census_nodes_closest, census_tris_closest, census_rays_closest;
 	uint64_t census_nodes_any, census_tris_any, census_rays_any;
+	double gather_ms;         /* summed device time of the photon gather (radiance_estimate) launches */
+	int64_t gather_launches;
+	int64_t gather_points;    /* shading points handed to the gather */
+	uint64_t census_gather_visits; /* census: photons in the grid cells the points' mandatory first pass reads */
 } rt_hip_stats;
 
 /* ---- life cycle --------------------------------------------------------------------------- */

@@ -51,7 +51,9 @@ class Stats(C.Structure):
                 ("bvh_depth", C.c_int32), ("reserved", C.c_int32), ("frame_ms", C.c_double), ("frames", C.c_int64),
                 ("census_nodes_closest", C.c_uint64), ("census_tris_closest", C.c_uint64),
                 ("census_rays_closest", C.c_uint64), ("census_nodes_any", C.c_uint64),
-                ("census_tris_any", C.c_uint64), ("census_rays_any", C.c_uint64)]
+                ("census_tris_any", C.c_uint64), ("census_rays_any", C.c_uint64),
+                ("gather_ms", C.c_double), ("gather_launches", C.c_int64), ("gather_points", C.c_int64),
+                ("census_gather_visits", C.c_uint64)]
 
 
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)

@@ -669,6 +669,18 @@ __global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const ui
 	}
 }
 
+// census: the photons the mandatory first pass of all points reads (the cells of each point's cube)
+__global__ __launch_bounds__(256) void k_photon_census(GridDesc gd, const uint32_t* __restrict__ cell_start,
+                                                       const float* __restrict__ qpos, int npts, float radius,
+                                                       unsigned long long* __restrict__ visits)
+{
+	int i = blockIdx.x * 256 + threadIdx.x;
+	unsigned long long v = 0;
+	if (i < npts) v = cube_population(gd, cell_start, ld3(qpos + 3 * (size_t)i), radius);
+	for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+	if (lane_id() == 0 && v) atomicAdd(visits, v);
+}
+
 float ord2f(uint32_t o)
 {
 	uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
@@ -795,6 +807,13 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	int* heavy_count = ctx->d_heavy.as<int>();
 	int* heavy_queue = heavy_count + 16;
 	RT_HIP_CHECK(hipMemsetAsync(heavy_count, 0, sizeof(int), ctx->stream));
+	ctx->stats.gather_points += npts;
+	if (unsigned long long* cen = ctx->num_photons > 0 ? rt_census_ptr(ctx, 2) : nullptr) {
+		hipLaunchKernelGGL(k_photon_census, dim3(nblocks(npts, 256)), dim3(256), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
+		                   d_pos, npts, radius, cen);
+		RT_HIP_CHECK(hipGetLastError());
+	}
+	RT_CHECK(rt_begin_trace_timing(ctx));
 	hipLaunchKernelGGL(k_photon_gather, dim3(nblocks(npts, GBLOCK)), dim3(GBLOCK), 0, ctx->stream, gd,
 	                   ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(),
 	                   ctx->num_photons, d_pos, d_nrm, npts, count, radius, gc, d_rgb, heavy, heavy_queue, heavy_count);
@@ -807,5 +826,6 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 		                   heavy_queue, heavy_count, count, radius, gc, d_rgb);
 		RT_HIP_CHECK(hipGetLastError());
 	}
+	RT_CHECK(rt_end_trace_timing(ctx, 2));
 	return RT_HIP_OK;
 }

@@ -175,7 +175,7 @@ int rt_begin_trace_timing(rt_hip_ctx* ctx, hipStream_t st)
 int rt_end_trace_timing(rt_hip_ctx* ctx, int cls, hipStream_t st)
 {
 	if (!st) st = ctx->stream;
-	if (cls) ctx->stats.any_launches += 1; else ctx->stats.closest_launches += 1;
+	if (cls == 2) ctx->stats.gather_launches += 1; else if (cls) ctx->stats.any_launches += 1; else ctx->stats.closest_launches += 1;
 	if (!ctx->cfg.profile) return RT_HIP_OK;
 	RT_HIP_CHECK(hipEventRecord(ctx->trace_events[ctx->trace_events_used].second, st));
 	ctx->trace_event_class[ctx->trace_events_used] = cls;
@@ -213,7 +213,7 @@ unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls)
 		if (ctx->d_census.reserve(64) != RT_HIP_OK) return nullptr;
 		if (hipMemset(ctx->d_census.p, 0, 64) != hipSuccess) return nullptr;  // synchronous: done before any kernel adds to it
 	}
-	return ctx->d_census.as<unsigned long long>() + (cls ? 3 : 0);
+	return ctx->d_census.as<unsigned long long>() + (cls == 2 ? 6 : cls ? 3 : 0);
 }
 
 // Fold the pending event pairs into stats (requires the stream to be idle or syncs on the events).
@@ -224,14 +224,17 @@ int rt_collect_timing(rt_hip_ctx* ctx)
 		RT_HIP_CHECK(hipEventSynchronize(ctx->trace_events[i].second));
 		float ms = 0;
 		RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->trace_events[i].first, ctx->trace_events[i].second));
-		if (ctx->trace_event_class[i]) ctx->stats.any_ms += ms; else ctx->stats.closest_ms += ms;
+		if (ctx->trace_event_class[i] == 2) ctx->stats.gather_ms += ms;
+		else if (ctx->trace_event_class[i]) ctx->stats.any_ms += ms;
+		else ctx->stats.closest_ms += ms;
 	}
 	ctx->trace_events_used = 0;
 	if (ctx->cfg.census && ctx->d_census.p) {
-		unsigned long long c[6];
+		unsigned long long c[7];
 		RT_HIP_CHECK(hipMemcpy(c, ctx->d_census.p, sizeof(c), hipMemcpyDeviceToHost));
 		ctx->stats.census_nodes_closest = c[0]; ctx->stats.census_tris_closest = c[1]; ctx->stats.census_rays_closest = c[2];
 		ctx->stats.census_nodes_any = c[3]; ctx->stats.census_tris_any = c[4]; ctx->stats.census_rays_any = c[5];
+		ctx->stats.census_gather_visits = c[6];
 	}
 	return RT_HIP_OK;
 }

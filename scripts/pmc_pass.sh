@@ -6,4 +6,4 @@ set -e
 name=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -o $name -- \
-    python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$name.log 2>&1
+    python3 bench.py ${PMC_BENCH_ARGS:---steps 2 --warmup 1 --frames-per-step 5 --no-cpu-baseline --no-extras} > gpurun_out/pmc_$name.log 2>&1
