@@ -124,6 +124,33 @@ typedef struct rt_hip_config {
 	int reserved;
 } rt_hip_config;
 
+/* What rt_hip_update found to do (rt_hip_stats.last_update). */
+enum rt_hip_update_kind {
+	RT_HIP_UPDATE_NONE = 0,    /* nothing changed since the last update */
+	RT_HIP_UPDATE_TABLES = 1,  /* materials / lights / textures re-uploaded, geometry untouched */
+	RT_HIP_UPDATE_REFIT = 2,   /* model matrices changed: soup rebuilt, boxes refitted on the kept BVH topology */
+	RT_HIP_UPDATE_REBUILD = 3  /* meshes added, first update, rt_hip_invalidate, or the refit quality check failed: built from scratch */
+};
+
+/* Launch-shape and algorithm knobs that are not part of the reference's semantics (results are the same for
+ * every setting; tests flip them to reach otherwise rare code paths).  rt_hip_create fills them with the defaults
+ * below, overridden by the environment variable named beside each (read once, at rt_hip_create) -- see
+ * INTEGRATION.md.  rt_hip_set_tuning takes effect at the next rt_hip_update where a build is involved. */
+typedef struct rt_hip_tuning {
+	int lds_stack_depth;      /* 16   RT_HIP_LDS_DEPTH: entries of a lane's traversal stack kept in LDS (1..32); the rest in HBM */
+	int xcd_chunk;            /* 64   RT_HIP_XCD_CHUNK: workgroups per XCD and group in the XCD-aware block order; 0 = hardware order */
+	int trace_oversub;        /* 4    RT_HIP_OVERSUB: grid cap of the trace kernels in units of the resident threads (1..16) */
+	int auto_accel;           /* RT_HIP_ACCEL_PLOC  RT_HIP_AUTO_PLOC=0 -> LBVH: what RT_HIP_ACCEL_AUTO builds from 512 triangles on */
+	int ploc_radius;          /* 8    RT_HIP_PLOC_RADIUS: PLOC nearest-neighbour search radius (1..64) */
+	int frame_sync;           /* 0    RT_HIP_FRAME_SYNC: 1 = frames are rendered level by level with counts read back */
+	uint32_t gather_heavy;    /* 1024 RT_HIP_GATHER_HEAVY: a shading point with more photons in its cube takes the wave-per-point gather */
+	int extra_lds_bytes;      /* 0    RT_HIP_EXTRA_LDS: extra LDS per trace workgroup (occupancy experiments) */
+	int max_bvh_depth;        /* 95   deepest BVH the traversal stack takes (<= 95); a deeper tree is not used: brute force serves the scene */
+	float refit_max_growth;   /* 2.0  RT_HIP_REFIT_GROWTH: refit is kept while (sum of node areas / root area) stays below this multiple
+	                                 of its value at the last build; 0 = never refit, always rebuild */
+	int reserved[6];
+} rt_hip_tuning;
+
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent
  * pairs around every trace launch on the context's stream); the census sums only when
  * config.census != 0 (the trace kernels then also count node visits and triangle tests). */
@@ -134,11 +161,11 @@ typedef struct rt_hip_stats {
 	double any_ms;            /* summed device time of any-hit (shadow) trace launches */
 	int64_t any_launches;
 	int64_t rays_any;         /* any-hit rays issued */
-	double build_ms;          /* last rt_hip_update: soup + LBVH build */
+	double build_ms;          /* device time of the last rt_hip_update that touched the geometry (soup + build, or soup + refit) */
 	int64_t num_tris;
 	int64_t num_nodes;
 	int32_t bvh_depth;
-	int32_t reserved;
+	int32_t last_update;      /* what the last rt_hip_update did: rt_hip_update_kind */
 	double frame_ms;          /* summed device time of whole frames (render / process entries) */
 	int64_t frames;
 	uint64_t census_nodes_closest, census_tris_closest, census_rays_closest;
@@ -147,6 +174,8 @@ typedef struct rt_hip_stats {
 	int64_t gather_launches;
 	int64_t gather_points;    /* shading points handed to the gather */
 	uint64_t census_gather_visits; /* census: photons in the grid cells the points' mandatory first pass reads */
+	double bvh_area_cost;       /* sum of the BVH nodes' surface areas / the root's: the tree in use (after a refit: the refitted boxes) */
+	double bvh_area_cost_built; /* the same when the topology was built; a refit is kept while cost <= tuning.refit_max_growth x this */
 } rt_hip_stats;
 
 /* ---- life cycle --------------------------------------------------------------------------- */
@@ -158,6 +187,8 @@ int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out);      /* RayTracer
 int rt_hip_destroy(rt_hip_ctx* ctx);
 const char* rt_hip_last_error(void);
 int rt_hip_set_config(rt_hip_ctx* ctx, const rt_hip_config* cfg);   /* shading/photon fields only */
+int rt_hip_get_tuning(rt_hip_ctx* ctx, rt_hip_tuning* out);
+int rt_hip_set_tuning(rt_hip_ctx* ctx, const rt_hip_tuning* tuning);
 
 /* ---- scene -------------------------------------------------------------------------------- */
 /* Scene::materials / Scene::lights (data/scene.h:8-10).  Material ids are indices into this table. */
@@ -178,12 +209,22 @@ int rt_hip_add_mesh(rt_hip_ctx* ctx, const float* verts, const float* normals, c
                     int nverts, const uint32_t* faces, int nfaces, const float* model_mat16,
                     int material_id, const float* position3);
 /* AccelSpheres::addSphere (rt_accel_spheres.cpp:14-26); the colour comes from libc
- * rand()%256 under srand(420) exactly as the reference draws it. */
+ * rand()%256 under srand(420) exactly as the reference draws it.  SIDE EFFECT, as in the reference
+ * (rt_accel_spheres.cpp:11,24): the first sphere of a context calls srand(420) and every sphere draws three
+ * numbers from the PROCESS-GLOBAL libc rand() stream, which perturbs any other user of rand() in the process
+ * (the reference's own PhotonMap::generate included). */
 int rt_hip_add_sphere(rt_hip_ctx* ctx, float x, float y, float z, float radius);
 int rt_hip_set_model_mat(rt_hip_ctx* ctx, int mesh_id, const float* model_mat16);
-/* IAccel::update (rt_iaccel.h:8): rebuild the world-space triangle soup (rt_raytracer.cpp:457-503)
- * and the LBVH on the GPU.  Must be called after the scene changes and before tracing. */
+/* IAccel::update (rt_iaccel.h:8): bring the device scene up to date.  Must be called after the scene changes
+ * and before tracing.  It does the least that the changes since the last update need (rt_hip_update_kind):
+ * nothing; the material / light / texture tables only; for changed model matrices (rt_hip_set_model_mat
+ * with a matrix that differs from the mesh's current one -- an equal matrix changes nothing) the world-space
+ * triangle soup of rt_raytracer.cpp:457-503 plus a bottom-up REFIT of the boxes on the kept BVH topology; a
+ * build from scratch when meshes were added, after rt_hip_invalidate, or when the refitted tree's area sum
+ * has grown past tuning.refit_max_growth.  Results never depend on which of these ran. */
 int rt_hip_update(rt_hip_ctx* ctx);
+/* The next rt_hip_update rebuilds everything from scratch. */
+int rt_hip_invalidate(rt_hip_ctx* ctx);
 
 /* ---- IAccel batch entries ------------------------------------------------------------------ */
 /* IAccel::intersect for n rays (rt_iaccel.h:10; rt_accel_array.cpp:75-137 / rt_accel_spheres.cpp:58-104).
@@ -265,7 +306,7 @@ int rt_hip_set_frame_texcoords_device(rt_hip_ctx* ctx, const float* const* d_uv,
  * render the same image: the default one sizes every level of the ray tree by its bound and never
  * returns to the host inside a frame; frames with a photon map, with more than 30 lights, or too
  * large to be sized by bounds are rendered level by level with counts read back (so is any frame
- * when RT_HIP_FRAME_SYNC=1). */
+ * when tuning.frame_sync = 1). */
 int rt_hip_render_frame(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float* gbuf_nrm_rgba, int width,
                         int height, uint8_t* rgba_out);
 int rt_hip_render_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba,
@@ -355,6 +396,12 @@ int rt_hip_radiance_estimate_device(rt_hip_ctx* ctx, const float* d_pos, const f
                                     int count, float radius, float* d_rgb_out);
 int rt_hip_radiance_estimate(rt_hip_ctx* ctx, const float* pos, const float* nrm, int npts, int count,
                              float radius, float* rgb_out);
+
+/* PhotonMap::lookup (rt_photon_map.cpp:126-142): the summed energy of the photons with |p - pos|^2 < radius^2
+ * at npts points (the reference has no caller for it).  The sum runs in grid order, not photon-index order:
+ * equal to the reference's to float rounding of the sum. */
+int rt_hip_photon_lookup_device(rt_hip_ctx* ctx, const float* d_pos, int npts, float radius, float* d_rgb_out);
+int rt_hip_photon_lookup(rt_hip_ctx* ctx, const float* pos, int npts, float radius, float* rgb_out);
 
 /* ---- introspection ------------------------------------------------------------------------- */
 int rt_hip_get_stats(rt_hip_ctx* ctx, rt_hip_stats* out);

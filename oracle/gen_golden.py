@@ -41,6 +41,7 @@ SCENES = {
     "cornell": scenes.cornell,
     "atrium2k": lambda: scenes.atrium(2048),
     "atrium2k_xf": lambda: scenes.with_transforms(scenes.atrium(2048)),
+    "atrium8k": lambda: scenes.atrium(8192),
     "spheres": scenes.sphere_field,
 }
 
@@ -128,9 +129,10 @@ def gen_camera():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    for n in ("cornell", "atrium2k", "atrium2k_xf"):
-        gen_process(n, 96, 72)
-    for n in ("cornell", "atrium2k"):
+    # Cornell, a 2k- and an 8k-triangle scene x 16k-64k G-buffer samples (160 x 120 = 19,200 texels)
+    for n in ("cornell", "atrium2k", "atrium2k_xf", "atrium8k"):
+        gen_process(n, 160, 120)
+    for n in ("cornell", "atrium2k", "atrium8k"):
         gen_array(n, 80, 60)
     gen_spheres()
     gen_photons()

@@ -48,13 +48,22 @@ class Stats(C.Structure):
     _fields_ = [("closest_ms", C.c_double), ("closest_launches", C.c_int64), ("rays_closest", C.c_int64),
                 ("any_ms", C.c_double), ("any_launches", C.c_int64), ("rays_any", C.c_int64),
                 ("build_ms", C.c_double), ("num_tris", C.c_int64), ("num_nodes", C.c_int64),
-                ("bvh_depth", C.c_int32), ("reserved", C.c_int32), ("frame_ms", C.c_double), ("frames", C.c_int64),
+                ("bvh_depth", C.c_int32), ("last_update", C.c_int32), ("frame_ms", C.c_double), ("frames", C.c_int64),
                 ("census_nodes_closest", C.c_uint64), ("census_tris_closest", C.c_uint64),
                 ("census_rays_closest", C.c_uint64), ("census_nodes_any", C.c_uint64),
                 ("census_tris_any", C.c_uint64), ("census_rays_any", C.c_uint64),
                 ("gather_ms", C.c_double), ("gather_launches", C.c_int64), ("gather_points", C.c_int64),
-                ("census_gather_visits", C.c_uint64)]
+                ("census_gather_visits", C.c_uint64), ("bvh_area_cost", C.c_double), ("bvh_area_cost_built", C.c_double)]
 
+
+class Tuning(C.Structure):
+    """rt_hip_tuning (include/rt_hip.h): knobs outside the reference's semantics."""
+    _fields_ = [("lds_stack_depth", C.c_int), ("xcd_chunk", C.c_int), ("trace_oversub", C.c_int), ("auto_accel", C.c_int),
+                ("ploc_radius", C.c_int), ("frame_sync", C.c_int), ("gather_heavy", C.c_uint32), ("extra_lds_bytes", C.c_int),
+                ("max_bvh_depth", C.c_int), ("refit_max_growth", C.c_float), ("reserved", C.c_int * 6)]
+
+
+UPDATE_NONE, UPDATE_TABLES, UPDATE_REFIT, UPDATE_REBUILD = 0, 1, 2, 3
 
 # every symbol include/rt_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -71,6 +80,7 @@ ABI_SYMBOLS = [
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device", "rt_hip_gbuffer_select_noalloc_device",
+    "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
 ]
 
 
@@ -151,6 +161,11 @@ def load_library() -> C.CDLL:
     L.rt_hip_unpack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
     L.rt_hip_shade_results.argtypes = [P, P, P, C.c_int, C.c_int, c_float_p, P]
     L.rt_hip_shade_results_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
+    L.rt_hip_get_tuning.argtypes = [P, C.POINTER(Tuning)]
+    L.rt_hip_set_tuning.argtypes = [P, C.POINTER(Tuning)]
+    L.rt_hip_invalidate.argtypes = [P]
+    L.rt_hip_photon_lookup_device.argtypes = [P, P, C.c_int, C.c_float, P]
+    L.rt_hip_photon_lookup.argtypes = [P, c_float_p, C.c_int, C.c_float, c_float_p]
     L.rt_hip_get_stats.argtypes = [P, C.POINTER(Stats)]
     L.rt_hip_reset_stats.argtypes = [P]
     L.rt_hip_sync.argtypes = [P]
@@ -211,7 +226,7 @@ class RtHip:
     """
 
     def __init__(self, scene=None, semantics="raytracer", geometry=TRIANGLES, accel=ACCEL_AUTO, device=0, profile=0,
-                 **cfg_overrides):
+                 tuning=None, **cfg_overrides):
         self.lib = load_library()
         self.cfg = Config()
         if semantics == "array":
@@ -226,6 +241,8 @@ class RtHip:
             setattr(self.cfg, k, v)
         self.h = C.c_void_p()
         self._ck(self.lib.rt_hip_create(C.byref(self.cfg), C.byref(self.h)))
+        if tuning:
+            self.set_tuning(**tuning)
         self.scene = None
         if scene is not None:
             self.load_scene(scene)
@@ -249,6 +266,16 @@ class RtHip:
     # ---- scene ----------------------------------------------------------------------------
     def load_scene(self, scene, update=True):
         self.scene = scene
+        self.load_scene_tables(scene)
+        for me in scene.meshes:
+            self._ck(self.lib.rt_hip_add_mesh(self.h, _p(me.verts), _p(me.normals), _p(me.texcoords), me.verts.shape[0],
+                                              _p(me.faces, c_u32_p), me.faces.shape[0], _p(me.model_colmajor()),
+                                              me.material, _p(_f(me.position))))
+        if update:
+            self.update()
+
+    def load_scene_tables(self, scene):
+        """Scene::materials (with their textures) and Scene::lights; takes effect at the next update()."""
         mats = np.zeros(len(scene.materials), MATERIAL_DTYPE)
         for i, m in enumerate(scene.materials):
             mats[i] = (m.diffuse, m.specular, m.shininess, m.reflectivity, m.alpha, m.ior, 0)
@@ -260,12 +287,6 @@ class RtHip:
         for i, li in enumerate(scene.lights):
             lights[i] = (li.position, li.color, li.energy)
         self._ck(self.lib.rt_hip_set_lights(self.h, lights.ctypes.data_as(C.c_void_p), len(lights)))
-        for me in scene.meshes:
-            self._ck(self.lib.rt_hip_add_mesh(self.h, _p(me.verts), _p(me.normals), _p(me.texcoords), me.verts.shape[0],
-                                              _p(me.faces, c_u32_p), me.faces.shape[0], _p(me.model_colmajor()),
-                                              me.material, _p(_f(me.position))))
-        if update:
-            self.update()
 
     def update(self):
         self._ck(self.lib.rt_hip_update(self.h))
@@ -285,6 +306,28 @@ class RtHip:
         """Mesh::model_mat of one mesh (column-major 4x4); takes effect at the next update()."""
         m = np.ascontiguousarray(model_colmajor16, dtype=np.float32).reshape(16)
         self._ck(self.lib.rt_hip_set_model_mat(self.h, int(mesh_id), _p(m)))
+
+    def tuning(self):
+        t = Tuning()
+        self._ck(self.lib.rt_hip_get_tuning(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Tuning._fields_ if k != "reserved"}
+
+    def set_tuning(self, **kw):
+        """rt_hip_set_tuning: launch-shape / algorithm knobs (results never depend on them)."""
+        t = Tuning()
+        self._ck(self.lib.rt_hip_get_tuning(self.h, C.byref(t)))
+        for k, v in kw.items():
+            if not hasattr(t, k):
+                raise AttributeError("rt_hip_tuning has no field %r" % k)
+            setattr(t, k, v)
+        self._ck(self.lib.rt_hip_set_tuning(self.h, C.byref(t)))
+
+    def invalidate(self):
+        """The next update() rebuilds from scratch."""
+        self._ck(self.lib.rt_hip_invalidate(self.h))
+
+    def force_rebuild(self):
+        self.invalidate()
 
     def set_config(self, **kw):
         for k, v in kw.items():
@@ -447,6 +490,16 @@ class RtHip:
         out = np.zeros_like(pos)
         self._ck(self.lib.rt_hip_radiance_estimate(self.h, _p(pos), _p(nrm), pos.shape[0], count, radius, _p(out)))
         return out
+
+    def photon_lookup(self, pos, radius=1.0):
+        """PhotonMap::lookup at each point: summed energy of the photons within `radius`."""
+        pos = _f(pos)
+        out = np.zeros_like(pos)
+        self._ck(self.lib.rt_hip_photon_lookup(self.h, _p(pos), pos.shape[0], radius, _p(out)))
+        return out
+
+    def photon_lookup_device(self, d_pos, npts, radius, d_out):
+        self._ck(self.lib.rt_hip_photon_lookup_device(self.h, _dptr(d_pos), npts, radius, _dptr(d_out)))
 
     def radiance_estimate_device(self, d_pos, d_nrm, npts, count, radius, d_out):
         self._ck(self.lib.rt_hip_radiance_estimate_device(self.h, _dptr(d_pos), _dptr(d_nrm), npts, count, radius, _dptr(d_out)))

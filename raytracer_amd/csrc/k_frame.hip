@@ -1510,9 +1510,8 @@ int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float
 	if (ctx->cfg.bounces > 8) { rt_set_error("bounces > 8 not supported"); return RT_HIP_ERR_LIMIT; }
 	if ((int)ctx->lights.size() > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
 	// The photon gather takes its point count on the host, so photon-mapped frames stay on the
-	// synchronous path.  RT_HIP_FRAME_SYNC=1 forces it (tests compare the two).
-	const char* e = getenv("RT_HIP_FRAME_SYNC");
-	const int force_sync = e ? atoi(e) : 0;
+	// synchronous path.  tuning.frame_sync forces it (tests compare the two).
+	const int force_sync = ctx->tuning.frame_sync;
 	// (more lights than the mask word has room for beside the child flags: the synchronous driver as well)
 	if (!ctx->cfg.use_photon_map && !force_sync && (int)ctx->lights.size() <= FRAME_ASYNC_MAX_LIGHTS) {
 		FrameSet fs;

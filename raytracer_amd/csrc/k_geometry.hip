@@ -133,79 +133,72 @@ void inverse_transpose(const float* m, float* out)
 
 }  // namespace
 
-int rt_build_geometry(rt_hip_ctx* ctx)
+// ---- materials / lights / textures / spheres -> device tables -------------------------------------
+static int upload_tables(rt_hip_ctx* ctx)
 {
 	hipStream_t st = ctx->stream;
-	// ---- materials / lights / spheres ----
-	{
-		// user materials first; for sphere geometry one material per sphere follows (the reference's
-		// `new Material` with only diffuse_color assigned, rt_accel_spheres.cpp:22-24; every other
-		// field is indeterminate there and defined as zero here)
-		const size_t nuser = ctx->materials.size();
-		const size_t nsph = ctx->cfg.geometry == RT_HIP_SPHERES ? ctx->spheres.size() : 0;
-		std::vector<MaterialRec> mr(nuser + nsph);
-		memset(mr.data(), 0, mr.size() * sizeof(MaterialRec));
-		for (size_t i = 0; i < nsph; ++i)
-			for (int k = 0; k < 3; ++k) mr[nuser + i].diffuse[k] = ctx->spheres[i].diffuse[k];
-		for (size_t i = 0; i < nuser; ++i) {
-			const rt_material& m = ctx->materials[i];
-			for (int k = 0; k < 3; ++k) { mr[i].diffuse[k] = m.diffuse_color[k]; mr[i].specular[k] = m.specular_color[k]; }
-			mr[i].shininess = m.shininess; mr[i].reflectivity = m.reflectivity; mr[i].alpha = m.alpha; mr[i].ior = m.ior;
-			mr[i].pad[0] = mr[i].pad[1] = 0;
-		}
-		RT_CHECK(ctx->d_materials.reserve(std::max<size_t>(mr.size(), 1) * sizeof(MaterialRec)));
-		if (!mr.empty())
-			RT_HIP_CHECK(hipMemcpyAsync(ctx->d_materials.p, mr.data(), mr.size() * sizeof(MaterialRec), hipMemcpyHostToDevice, st));
-		// textures: one record per material, texels of all textures in one pool
-		ctx->any_texture = false;
-		for (size_t i = 0; i < ctx->textures.size() && i < nuser; ++i) ctx->any_texture |= ctx->textures[i].w > 0;
-		if (ctx->any_texture) {
-			std::vector<TexRec> tr(mr.size());
-			memset(tr.data(), 0, tr.size() * sizeof(TexRec));
-			std::vector<uint32_t> pool;
-			for (size_t i = 0; i < ctx->textures.size() && i < nuser; ++i) {
-				const HostTexture& t = ctx->textures[i];
-				if (t.w <= 0) continue;
-				tr[i].offset = (uint32_t)pool.size(); tr[i].w = t.w; tr[i].h = t.h;
-				pool.insert(pool.end(), t.texels.begin(), t.texels.end());
-			}
-			RT_CHECK(ctx->d_tex.reserve(tr.size() * sizeof(TexRec)));
-			RT_CHECK(ctx->d_texels.reserve(pool.size() * 4));
-			RT_HIP_CHECK(hipMemcpy(ctx->d_tex.p, tr.data(), tr.size() * sizeof(TexRec), hipMemcpyHostToDevice));
-			RT_HIP_CHECK(hipMemcpy(ctx->d_texels.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
-		}
-		std::vector<LightRec> lr(ctx->lights.size());
-		for (size_t i = 0; i < lr.size(); ++i) {
-			for (int k = 0; k < 3; ++k) { lr[i].position[k] = ctx->lights[i].position[k]; lr[i].color[k] = ctx->lights[i].color[k]; }
-			lr[i].energy = ctx->lights[i].energy; lr[i].pad = 0;
-		}
-		RT_CHECK(ctx->d_lights.reserve(std::max<size_t>(lr.size(), 1) * sizeof(LightRec)));
-		if (!lr.empty())
-			RT_HIP_CHECK(hipMemcpyAsync(ctx->d_lights.p, lr.data(), lr.size() * sizeof(LightRec), hipMemcpyHostToDevice, st));
-		std::vector<SphereRec> sr(ctx->spheres.size());
-		for (size_t i = 0; i < sr.size(); ++i) {
-			sr[i].cx = ctx->spheres[i].c[0]; sr[i].cy = ctx->spheres[i].c[1]; sr[i].cz = ctx->spheres[i].c[2];
-			sr[i].r = ctx->spheres[i].r;
-		}
-		RT_CHECK(ctx->d_spheres.reserve(std::max<size_t>(sr.size(), 1) * sizeof(SphereRec)));
-		if (!sr.empty())
-			RT_HIP_CHECK(hipMemcpyAsync(ctx->d_spheres.p, sr.data(), sr.size() * sizeof(SphereRec), hipMemcpyHostToDevice, st));
-		RT_HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors die here
+	// user materials first; for sphere geometry one material per sphere follows (the reference's
+	// `new Material` with only diffuse_color assigned, rt_accel_spheres.cpp:22-24; every other
+	// field is indeterminate there and defined as zero here)
+	const size_t nuser = ctx->materials.size();
+	const size_t nsph = ctx->cfg.geometry == RT_HIP_SPHERES ? ctx->spheres.size() : 0;
+	std::vector<MaterialRec> mr(nuser + nsph);
+	memset(mr.data(), 0, mr.size() * sizeof(MaterialRec));
+	for (size_t i = 0; i < nsph; ++i)
+		for (int k = 0; k < 3; ++k) mr[nuser + i].diffuse[k] = ctx->spheres[i].diffuse[k];
+	for (size_t i = 0; i < nuser; ++i) {
+		const rt_material& m = ctx->materials[i];
+		for (int k = 0; k < 3; ++k) { mr[i].diffuse[k] = m.diffuse_color[k]; mr[i].specular[k] = m.specular_color[k]; }
+		mr[i].shininess = m.shininess; mr[i].reflectivity = m.reflectivity; mr[i].alpha = m.alpha; mr[i].ior = m.ior;
+		mr[i].pad[0] = mr[i].pad[1] = 0;
 	}
+	RT_CHECK(ctx->d_materials.reserve(std::max<size_t>(mr.size(), 1) * sizeof(MaterialRec)));
+	if (!mr.empty())
+		RT_HIP_CHECK(hipMemcpyAsync(ctx->d_materials.p, mr.data(), mr.size() * sizeof(MaterialRec), hipMemcpyHostToDevice, st));
+	// textures: one record per material, texels of all textures in one pool
+	ctx->any_texture = false;
+	for (size_t i = 0; i < ctx->textures.size() && i < nuser; ++i) ctx->any_texture |= ctx->textures[i].w > 0;
+	if (ctx->any_texture) {
+		std::vector<TexRec> tr(mr.size());
+		memset(tr.data(), 0, tr.size() * sizeof(TexRec));
+		std::vector<uint32_t> pool;
+		for (size_t i = 0; i < ctx->textures.size() && i < nuser; ++i) {
+			const HostTexture& t = ctx->textures[i];
+			if (t.w <= 0) continue;
+			tr[i].offset = (uint32_t)pool.size(); tr[i].w = t.w; tr[i].h = t.h;
+			pool.insert(pool.end(), t.texels.begin(), t.texels.end());
+		}
+		RT_CHECK(ctx->d_tex.reserve(tr.size() * sizeof(TexRec)));
+		RT_CHECK(ctx->d_texels.reserve(pool.size() * 4));
+		RT_HIP_CHECK(hipMemcpy(ctx->d_tex.p, tr.data(), tr.size() * sizeof(TexRec), hipMemcpyHostToDevice));
+		RT_HIP_CHECK(hipMemcpy(ctx->d_texels.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
+	}
+	std::vector<LightRec> lr(ctx->lights.size());
+	for (size_t i = 0; i < lr.size(); ++i) {
+		for (int k = 0; k < 3; ++k) { lr[i].position[k] = ctx->lights[i].position[k]; lr[i].color[k] = ctx->lights[i].color[k]; }
+		lr[i].energy = ctx->lights[i].energy; lr[i].pad = 0;
+	}
+	RT_CHECK(ctx->d_lights.reserve(std::max<size_t>(lr.size(), 1) * sizeof(LightRec)));
+	if (!lr.empty())
+		RT_HIP_CHECK(hipMemcpyAsync(ctx->d_lights.p, lr.data(), lr.size() * sizeof(LightRec), hipMemcpyHostToDevice, st));
+	std::vector<SphereRec> sr(ctx->spheres.size());
+	for (size_t i = 0; i < sr.size(); ++i) {
+		sr[i].cx = ctx->spheres[i].c[0]; sr[i].cy = ctx->spheres[i].c[1]; sr[i].cz = ctx->spheres[i].c[2];
+		sr[i].r = ctx->spheres[i].r;
+	}
+	RT_CHECK(ctx->d_spheres.reserve(std::max<size_t>(sr.size(), 1) * sizeof(SphereRec)));
+	if (!sr.empty())
+		RT_HIP_CHECK(hipMemcpyAsync(ctx->d_spheres.p, sr.data(), sr.size() * sizeof(SphereRec), hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors die here
+	return RT_HIP_OK;
+}
 
-	// ---- concatenate mesh inputs (host) and upload ----
-	size_t nv = 0, nt = 0;
-	for (auto& m : ctx->meshes) { m.vert_offset = nv; m.first_tri = (uint32_t)nt; nv += m.verts.size() / 3; nt += m.faces.size() / 3; }
-	if (nt > 0x7FFFFFF0ull) { rt_set_error("too many triangles (%zu)", nt); return RT_HIP_ERR_LIMIT; }
-	ctx->num_tris = (int)nt;
-	ctx->num_nodes = 0;
-	ctx->use_bvh = 0;
-	ctx->bvh_depth = 0;
-	if (nt == 0) return RT_HIP_OK;
-
+// ---- concatenated mesh arrays (only when meshes were added) -----------------------------------------
+static int upload_meshes(rt_hip_ctx* ctx, size_t nv, size_t nt)
+{
+	hipStream_t st = ctx->stream;
 	std::vector<float> hv(nv * 3), hn(nv * 3), ht(nv * 2);
 	std::vector<uint32_t> hf(nt * 3), hm(nt);
-	std::vector<MeshXf> hx(ctx->meshes.size());
 	for (size_t mi = 0; mi < ctx->meshes.size(); ++mi) {
 		const HostMesh& m = ctx->meshes[mi];
 		size_t mv = m.verts.size() / 3, mf = m.faces.size() / 3;
@@ -216,50 +209,64 @@ int rt_build_geometry(rt_hip_ctx* ctx)
 		}
 		for (size_t f = 0; f < mf * 3; ++f) hf[(size_t)m.first_tri * 3 + f] = m.faces[f] + (uint32_t)m.vert_offset;
 		for (size_t f = 0; f < mf; ++f) hm[m.first_tri + f] = (uint32_t)mi;
-		memcpy(hx[mi].model, m.model, sizeof(m.model));
-		inverse_transpose(m.model, hx[mi].normal);
-		hx[mi].material = m.material;
-		hx[mi].use = ctx->cfg.use_model_mat ? 1 : 0;
-		hx[mi].pad[0] = hx[mi].pad[1] = 0;
 	}
 	RT_CHECK(ctx->d_verts.reserve(hv.size() * 4));
 	RT_CHECK(ctx->d_normals.reserve(hn.size() * 4));
 	RT_CHECK(ctx->d_texcoords.reserve(ht.size() * 4));
 	RT_CHECK(ctx->d_faces.reserve(hf.size() * 4));
 	RT_CHECK(ctx->d_mesh_of_tri.reserve(hm.size() * 4));
-	RT_CHECK(ctx->d_mesh_xf.reserve(hx.size() * sizeof(MeshXf)));
 	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_verts.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, st));
 	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_normals.p, hn.data(), hn.size() * 4, hipMemcpyHostToDevice, st));
 	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_texcoords.p, ht.data(), ht.size() * 4, hipMemcpyHostToDevice, st));
 	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_faces.p, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, st));
 	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_mesh_of_tri.p, hm.data(), hm.size() * 4, hipMemcpyHostToDevice, st));
-	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_mesh_xf.p, hx.data(), hx.size() * sizeof(MeshXf), hipMemcpyHostToDevice, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors die here
+	return RT_HIP_OK;
+}
 
-	RT_CHECK(ctx->d_tri_pos.reserve(nt * sizeof(TriPos)));
-	RT_CHECK(ctx->d_tri_attr.reserve(nt * sizeof(TriAttr)));
-	RT_CHECK(ctx->d_tri_isect.reserve(nt * sizeof(TriIsect)));
-	RT_CHECK(ctx->d_tri_box.reserve(nt * 2 * sizeof(float4)));
+// ---- per-mesh matrices (every update that touches the geometry; a few hundred bytes) -------------------
+static int upload_xf(rt_hip_ctx* ctx)
+{
+	std::vector<MeshXf> hx(ctx->meshes.size());
+	for (size_t mi = 0; mi < ctx->meshes.size(); ++mi) {
+		const HostMesh& m = ctx->meshes[mi];
+		memcpy(hx[mi].model, m.model, sizeof(m.model));
+		inverse_transpose(m.model, hx[mi].normal);
+		hx[mi].material = m.material;
+		hx[mi].use = ctx->cfg.use_model_mat ? 1 : 0;
+		hx[mi].pad[0] = hx[mi].pad[1] = 0;
+	}
+	RT_CHECK(ctx->d_mesh_xf.reserve(std::max<size_t>(hx.size(), 1) * sizeof(MeshXf)));
+	if (!hx.empty()) RT_HIP_CHECK(hipMemcpy(ctx->d_mesh_xf.p, hx.data(), hx.size() * sizeof(MeshXf), hipMemcpyHostToDevice));
+	return RT_HIP_OK;
+}
+
+// The world-space soup (rt_raytracer.cpp:457-503) into tri_pos / tri_attr / tri_box and `isect_out` (original
+// order), and the scene bounds back on the host.
+static int run_soup(rt_hip_ctx* ctx, TriIsect* isect_out)
+{
+	hipStream_t st = ctx->stream;
+	const size_t nt = (size_t)ctx->num_tris;
 	RT_CHECK(ctx->d_bounds.reserve(64));
-	uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_bounds.p, init, sizeof(init), hipMemcpyHostToDevice, st));
-
-	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+	uint32_t* h = (uint32_t*)ctx->h_small + 768;  // pinned
+	const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+	memcpy(h, init, sizeof(init));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_bounds.p, h, sizeof(init), hipMemcpyHostToDevice, st));
 	hipLaunchKernelGGL(k_soup, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, ctx->d_verts.as<float>(),
 	                   ctx->d_normals.as<float>(), ctx->d_texcoords.as<float>(), ctx->d_faces.as<uint32_t>(),
 	                   ctx->d_mesh_of_tri.as<uint32_t>(), ctx->d_mesh_xf.as<MeshXf>(), (int)nt,
-	                   ctx->d_tri_pos.as<TriPos>(), ctx->d_tri_attr.as<TriAttr>(), ctx->d_tri_isect.as<TriIsect>(),
+	                   ctx->d_tri_pos.as<TriPos>(), ctx->d_tri_attr.as<TriAttr>(), isect_out,
 	                   ctx->d_tri_box.as<float4>(), ctx->d_bounds.as<uint32_t>());
 	RT_HIP_CHECK(hipGetLastError());
-	uint32_t ob[6];
-	RT_HIP_CHECK(hipMemcpyAsync(ob, ctx->d_bounds.p, sizeof(ob), hipMemcpyDeviceToHost, st));
-	RT_HIP_CHECK(hipStreamSynchronize(st));  // also keeps hv..hx alive until the copies are done
-	for (int k = 0; k < 6; ++k) ctx->bounds[k] = ord2f(ob[k]);
+	RT_HIP_CHECK(hipMemcpyAsync(h + 8, ctx->d_bounds.p, sizeof(init), hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	for (int k = 0; k < 6; ++k) ctx->bounds[k] = ord2f(h[8 + k]);
+	return RT_HIP_OK;
+}
 
-	bool want_bvh = ctx->cfg.accel == RT_HIP_ACCEL_LBVH || ctx->cfg.accel == RT_HIP_ACCEL_PLOC ||
-	                ctx->cfg.accel == RT_HIP_ACCEL_SAH ||
-	                (ctx->cfg.accel == RT_HIP_ACCEL_AUTO && nt >= 512);
-	if (want_bvh && nt >= 2) RT_CHECK(rt_build_lbvh(ctx));
-	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+static int finish_geometry_timing(rt_hip_ctx* ctx, int kind)
+{
+	RT_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
 	RT_HIP_CHECK(hipEventSynchronize(ctx->ev1));
 	float ms = 0;
 	RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -267,5 +274,61 @@ int rt_build_geometry(rt_hip_ctx* ctx)
 	ctx->stats.num_tris = ctx->num_tris;
 	ctx->stats.num_nodes = ctx->num_nodes;
 	ctx->stats.bvh_depth = ctx->bvh_depth;
+	ctx->stats.last_update = kind;
+	ctx->stats.bvh_area_cost = ctx->use_bvh ? ctx->bvh_cost_now : 0.0;
+	ctx->stats.bvh_area_cost_built = ctx->use_bvh ? ctx->bvh_cost_built : 0.0;
 	return RT_HIP_OK;
+}
+
+int rt_build_geometry(rt_hip_ctx* ctx)
+{
+	hipStream_t st = ctx->stream;
+	if (ctx->dirty_tables || ctx->dirty_topology) RT_CHECK(upload_tables(ctx));
+	if (!ctx->dirty_topology && !ctx->dirty_xf) { ctx->stats.last_update = RT_HIP_UPDATE_TABLES; return RT_HIP_OK; }
+
+	const bool want_bvh_kind = ctx->cfg.accel == RT_HIP_ACCEL_LBVH || ctx->cfg.accel == RT_HIP_ACCEL_PLOC ||
+	                           ctx->cfg.accel == RT_HIP_ACCEL_SAH || ctx->cfg.accel == RT_HIP_ACCEL_AUTO;
+	// ---- refit: only model matrices changed -------------------------------------------------------
+	if (!ctx->dirty_topology && ctx->num_tris > 0 && ctx->tuning.refit_max_growth > 0.0f) {
+		RT_CHECK(upload_xf(ctx));
+		RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+		if (!ctx->use_bvh && !(want_bvh_kind && ctx->num_nodes > 0)) {
+			// brute-force scenes: the soup is all there is
+			RT_CHECK(run_soup(ctx, ctx->d_tri_isect.as<TriIsect>()));
+			return finish_geometry_timing(ctx, RT_HIP_UPDATE_REFIT);
+		}
+		if (ctx->use_bvh) {
+			RT_CHECK(ctx->d_in_a.reserve((size_t)ctx->num_tris * sizeof(TriIsect)));
+			RT_CHECK(run_soup(ctx, ctx->d_in_a.as<TriIsect>()));
+			float cost = 0.0f;
+			RT_CHECK(rt_refit_lbvh(ctx, ctx->d_in_a.as<TriIsect>(), &cost));
+			ctx->bvh_cost_now = cost;
+			if (cost <= ctx->tuning.refit_max_growth * ctx->bvh_cost_built) return finish_geometry_timing(ctx, RT_HIP_UPDATE_REFIT);
+			// the tree no longer fits the geometry: fall through to a build from scratch (matrices are uploaded already)
+		}
+	}
+
+	// ---- everything from scratch --------------------------------------------------------------------
+	size_t nv = 0, nt = 0;
+	for (auto& m : ctx->meshes) { m.vert_offset = nv; m.first_tri = (uint32_t)nt; nv += m.verts.size() / 3; nt += m.faces.size() / 3; }
+	if (nt > 0x7FFFFFF0ull) { rt_set_error("too many triangles (%zu)", nt); return RT_HIP_ERR_LIMIT; }
+	ctx->num_tris = (int)nt;
+	ctx->num_nodes = 0;
+	ctx->use_bvh = 0;
+	ctx->bvh_depth = 0;
+	if (nt == 0) { ctx->stats.last_update = RT_HIP_UPDATE_REBUILD; ctx->stats.num_tris = 0; ctx->stats.num_nodes = 0; ctx->stats.bvh_depth = 0; return RT_HIP_OK; }
+	if (ctx->dirty_topology) RT_CHECK(upload_meshes(ctx, nv, nt));
+	RT_CHECK(upload_xf(ctx));
+	RT_CHECK(ctx->d_tri_pos.reserve(nt * sizeof(TriPos)));
+	RT_CHECK(ctx->d_tri_attr.reserve(nt * sizeof(TriAttr)));
+	RT_CHECK(ctx->d_tri_isect.reserve(nt * sizeof(TriIsect)));
+	RT_CHECK(ctx->d_tri_box.reserve(nt * 2 * sizeof(float4)));
+
+	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+	RT_CHECK(run_soup(ctx, ctx->d_tri_isect.as<TriIsect>()));
+	bool want_bvh = ctx->cfg.accel == RT_HIP_ACCEL_LBVH || ctx->cfg.accel == RT_HIP_ACCEL_PLOC ||
+	                ctx->cfg.accel == RT_HIP_ACCEL_SAH ||
+	                (ctx->cfg.accel == RT_HIP_ACCEL_AUTO && nt >= 512);
+	if (want_bvh && nt >= 2) RT_CHECK(rt_build_lbvh(ctx));
+	return finish_geometry_timing(ctx, RT_HIP_UPDATE_REBUILD);
 }

@@ -419,7 +419,44 @@ __global__ __launch_bounds__(256) void k_depth(const int* __restrict__ node_pare
 	if ((threadIdx.x & 63) == 0) atomicMax(max_depth, d);
 }
 
+// Refit quality: sum of the half-areas of the internal nodes' boxes (slots [0, n-1)) -- the SAH cost of the
+// tree's inner part up to the constant root area, which the host divides by.
+__global__ __launch_bounds__(256) void k_area_sum(const BoxSlot* __restrict__ slots, int n_internal, float* __restrict__ sum)
+{
+	__shared__ float ws[4];
+	int i = blockIdx.x * 256 + threadIdx.x;
+	float a = 0.0f;
+	if (i < n_internal) {
+		const BoxSlot& s = slots[i];
+		const float dx = s.mx[0] - s.mn[0], dy = s.mx[1] - s.mn[1], dz = s.mx[2] - s.mn[2];
+		a = dx * dy + (dy * dz + dz * dx);
+	}
+	for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+	if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = a;
+	__syncthreads();
+	if (threadIdx.x == 0) atomicAdd(sum, (ws[0] + ws[1]) + (ws[2] + ws[3]));
+}
+
 }  // namespace
+
+// Area sum of the internal nodes relative to the root's (node 0) area; the slots must be complete.
+static int tree_cost(rt_hip_ctx* ctx, const BoxSlot* slots, int n, float* cost)
+{
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_bounds.reserve(64));
+	float* d_sum = ctx->d_bounds.as<float>() + 8;
+	RT_HIP_CHECK(hipMemsetAsync(d_sum, 0, 4, st));
+	hipLaunchKernelGGL(k_area_sum, dim3((n - 1 + 255) / 256), dim3(256), 0, st, slots, n - 1, d_sum);
+	RT_HIP_CHECK(hipGetLastError());
+	float* h = (float*)ctx->h_small + 512;  // pinned
+	RT_HIP_CHECK(hipMemcpyAsync(h, d_sum, 4, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipMemcpyAsync(h + 1, slots, 24, hipMemcpyDeviceToHost, st));  // the root's box
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	const float dx = h[4] - h[1], dy = h[5] - h[2], dz = h[6] - h[3];
+	const float root = dx * dy + (dy * dz + dz * dx);
+	*cost = root > 0.0f ? h[0] / root : 0.0f;
+	return RT_HIP_OK;
+}
 
 // PLOC rounds on the sorted leaves: fills left/right/node_parent/leaf_parent and every node's box slot.
 static int build_ploc(rt_hip_ctx* ctx, int n, float pad, const uint32_t* order, int* left, int* right,
@@ -427,8 +464,7 @@ static int build_ploc(rt_hip_ctx* ctx, int n, float pad, const uint32_t* order, 
 {
 	hipStream_t st = ctx->stream;
 	// search radius: 8 measured best on atrium-262k (nodes/ray 28.1; 16: 30.3, 32: 28.5, 64: 30.7; LBVH 31.4)
-	int r = 8;
-	if (const char* e = getenv("RT_HIP_PLOC_RADIUS")) r = std::min(PR_MAX, std::max(1, atoi(e)));
+	const int r = std::min(PR_MAX, std::max(1, ctx->tuning.ploc_radius));
 	const int nb0 = (n + PB - 1) / PB;
 	// scratch: 2 cluster lists, 2 cluster box lists, nn, flag, block counts, totals
 	size_t bytes = (size_t)n * (2 * 4 + 2 * sizeof(CBox) + 4 + 1) + (size_t)nb0 * sizeof(int2) + 256 + 64;
@@ -658,7 +694,8 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 	BoxSlot* slots = ctx->d_misc.as<BoxSlot>();
 
 	float pad = 1e-5f * emax;
-	const bool ploc = ctx->cfg.accel == RT_HIP_ACCEL_PLOC || (ctx->cfg.accel == RT_HIP_ACCEL_AUTO && rt_auto_ploc());
+	const bool ploc = ctx->cfg.accel == RT_HIP_ACCEL_PLOC ||
+	                  (ctx->cfg.accel == RT_HIP_ACCEL_AUTO && ctx->tuning.auto_accel == RT_HIP_ACCEL_PLOC);
 	if (sah) {
 		RT_CHECK(build_sah_host(ctx, n, pad, order, left, right, node_parent, leaf_parent, slots));
 	} else if (ploc) {
@@ -691,15 +728,69 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	ctx->bvh_depth = depth;
 	ctx->num_nodes = n - 1;
-	if (depth + 1 > 96) {
-		// pathological (massively duplicated centres): fall back to brute force rather than overflow
-		rt_set_error("BVH depth %d exceeds the traversal stack limit (96)", depth);
-		return RT_HIP_ERR_LIMIT;
+	// kept for refits: the leaf order (d_order is scratch that the photon grid reuses) and the tree's area sum
+	RT_CHECK(ctx->d_leaf_order.reserve((size_t)n * 4));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_leaf_order.p, order, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+	RT_CHECK(tree_cost(ctx, slots, n, &ctx->bvh_cost_built));
+	ctx->bvh_cost_now = ctx->bvh_cost_built;
+	if (depth > ctx->tuning.max_bvh_depth) {
+		// pathological input (PLOC has no depth bound on masses of coincident triangles): the tree is not used,
+		// brute force over the same records serves the scene
+		if (!ctx->warned_depth) {
+			ctx->warned_depth = true;
+			fprintf(stderr, "librt_hip: BVH depth %d exceeds the traversal stack limit (%d); tracing %d triangles by brute force\n",
+			        depth, ctx->tuning.max_bvh_depth, n);
+		}
+		ctx->use_bvh = 0;
+		ctx->bvh_depth = 0;
+		return RT_HIP_OK;
 	}
-	// overflow part of the traversal stacks: entries beyond the LDS-resident ones, one column per
-	// thread of a persistent trace launch
-	int over = depth + 1 - rt_lds_depth();
-	if (over > 0) RT_CHECK(ctx->d_spill.reserve((size_t)over * ctx->max_trace_threads * sizeof(int)));
 	ctx->use_bvh = 1;
+	RT_CHECK(rt_reserve_spill(ctx));
+	return RT_HIP_OK;
+}
+
+// Overflow part of the traversal stacks: the entries beyond the LDS-resident ones, one column per thread of the
+// largest trace grid (rt_trace_blocks never launches more than max_trace_threads).
+int rt_reserve_spill(rt_hip_ctx* ctx)
+{
+	const int over = ctx->bvh_depth + 1 - ctx->tuning.lds_stack_depth;
+	if (ctx->use_bvh && over > 0) RT_CHECK(ctx->d_spill.reserve((size_t)over * ctx->max_trace_threads * sizeof(int)));
+	return RT_HIP_OK;
+}
+
+// Refit: the boxes of the kept topology (left / right / parents in d_parent_leaf, leaf order in d_leaf_order) from
+// the triangle boxes k_soup has just rewritten; new quantisation grid over the new scene bounds, new traversal
+// nodes, leaf records permuted into the kept order.  Everything a build writes except the topology.
+int rt_refit_lbvh(rt_hip_ctx* ctx, const TriIsect* d_isect_src, float* cost)
+{
+	hipStream_t st = ctx->stream;
+	const int n = ctx->num_tris;
+	const int g = (n + 255) / 256;
+	int* left = ctx->d_parent_leaf.as<int>();
+	int* right = left + n;
+	int* node_parent = right + n;
+	int* leaf_parent = node_parent + n;
+	unsigned int* arrive = ctx->d_flags.as<unsigned int>();
+	BoxSlot* slots = ctx->d_misc.as<BoxSlot>();
+	const uint32_t* order = ctx->d_leaf_order.as<uint32_t>();
+	float emax = 0.0f;
+	for (int k = 0; k < 3; ++k) emax = std::max(emax, ctx->bounds[3 + k] - ctx->bounds[k]);
+	if (!(emax > 0.0f)) emax = 1.0f;
+	const float pad = 1e-5f * emax;
+	RT_HIP_CHECK(hipMemsetAsync(arrive, 0, (size_t)n * 4, st));
+	hipLaunchKernelGGL(k_refit, dim3(g), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad, left, right, node_parent,
+	                   leaf_parent, slots, arrive);
+	for (int k = 0; k < 3; ++k) {
+		ctx->qframe.org[k] = ctx->bounds[k] - 2.0f * pad;
+		float e = (ctx->bounds[3 + k] + 2.0f * pad) - ctx->qframe.org[k];
+		ctx->qframe.scale[k] = e > 0.0f ? e / 65535.0f : 1.0f;
+		ctx->qframe.reach[k] = std::fabs(ctx->qframe.org[k]) + 65535.0f * ctx->qframe.scale[k];
+	}
+	hipLaunchKernelGGL(k_emit_nodes, dim3(g), dim3(256), 0, st, slots, n, left, right, node_parent, ctx->d_nodes.as<BvhNode>(),
+	                   ctx->qframe, ctx->d_qnodes.as<QNode>());
+	hipLaunchKernelGGL(k_permute_tris, dim3(g), dim3(256), 0, st, d_isect_src, order, n, ctx->d_tri_isect.as<TriIsect>());
+	RT_HIP_CHECK(hipGetLastError());
+	RT_CHECK(tree_cost(ctx, slots, n, cost));
 	return RT_HIP_OK;
 }

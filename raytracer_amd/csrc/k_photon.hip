@@ -669,6 +669,31 @@ __global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const ui
 	}
 }
 
+// PhotonMap::lookup (rt_photon_map.cpp:126-142): the energies of the photons with l2 < r^2, one wave per point:
+// lane partial sums in walk order, then a butterfly (deterministic, but not the reference's index order).
+__global__ __launch_bounds__(64) void k_photon_lookup(GridDesc gd, const uint32_t* __restrict__ cell_start,
+                                                      const float4* __restrict__ pos, const float4* __restrict__ payload,
+                                                      const float* __restrict__ qpos, int npts, float radius,
+                                                      float* __restrict__ rgb)
+{
+	const float r2 = radius * radius;
+	for (int i = blockIdx.x; i < npts; i += gridDim.x) {
+		f3 P;
+		P.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 0])));
+		P.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 1])));
+		P.z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 2])));
+		f3 sum = mk3(0, 0, 0);
+		for_each_neighbour_wave(gd, cell_start, pos, P, radius, [&](uint32_t s, float l2, bool act) {
+			if (act && l2 < r2) {
+				const float4 a = payload[2 * (size_t)s];
+				sum = sum + mk3(a.x, a.y, a.z);
+			}
+		});
+		sum.x = wave_sum_f(sum.x); sum.y = wave_sum_f(sum.y); sum.z = wave_sum_f(sum.z);
+		if (lane_id() == 0) st3(rgb + 3 * (size_t)i, sum);
+	}
+}
+
 // census: the photons the mandatory first pass of all points reads (the cells of each point's cube)
 __global__ __launch_bounds__(256) void k_photon_census(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                        const float* __restrict__ qpos, int npts, float radius,
@@ -799,10 +824,9 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	gc.gauss_denom = 1 / (1 - powf(E, -BETA));
 	gc.two_pi = 2 * PI;
 	// points with more than `heavy` photons in their cube go to the wave-per-point kernel (queue and count stay
-	// on the device).  RT_HIP_GATHER_HEAVY overrides the threshold (0: every point with a photon nearby takes
+	// on the device).  tuning.gather_heavy is the threshold (0: every point with a photon nearby takes
 	// the wave kernel; a huge value: none does) -- the parity tests run both extremes.
-	uint32_t heavy = 1024;
-	if (const char* e = getenv("RT_HIP_GATHER_HEAVY")) heavy = (uint32_t)strtoul(e, nullptr, 10);
+	const uint32_t heavy = ctx->tuning.gather_heavy;
 	RT_CHECK(ctx->d_heavy.reserve(((size_t)npts + 16) * sizeof(int)));
 	int* heavy_count = ctx->d_heavy.as<int>();
 	int* heavy_queue = heavy_count + 16;
@@ -827,5 +851,21 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_CHECK(rt_end_trace_timing(ctx, 2));
+	return RT_HIP_OK;
+}
+
+int rt_photon_lookup(rt_hip_ctx* ctx, const float* d_pos, int npts, float radius, float* d_rgb)
+{
+	if (npts <= 0) return RT_HIP_OK;
+	if (ctx->num_photons == 0) {   // an empty map sums to zero (rt_photon_map.cpp:130)
+		RT_HIP_CHECK(hipMemsetAsync(d_rgb, 0, (size_t)npts * 12, ctx->stream));
+		return RT_HIP_OK;
+	}
+	GridDesc gd;
+	for (int k = 0; k < 3; ++k) { gd.mn[k] = ctx->photon_grid_min[k]; gd.dim[k] = ctx->photon_grid_dim[k]; }
+	gd.cell = ctx->photon_cell; gd.inv_cell = 1.0f / ctx->photon_cell;
+	hipLaunchKernelGGL(k_photon_lookup, dim3(std::min(npts, 64 * 1024)), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
+	                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), d_pos, npts, radius, d_rgb);
+	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }

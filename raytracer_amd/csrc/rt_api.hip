@@ -69,50 +69,58 @@ int rt_ensure_pinned(void** p, size_t* cap, size_t bytes)
 	return RT_HIP_OK;
 }
 
-size_t rt_debug_extra_lds()
+static int env_int(const char* name, int dflt)
 {
-	static long v = -1;
-	if (v < 0) { const char* e = getenv("RT_HIP_EXTRA_LDS"); v = e ? atol(e) : 0; }
-	return (size_t)v;
+	const char* e = getenv(name);
+	return e ? atoi(e) : dflt;
 }
 
-// Workgroups per XCD and group in the XCD-aware block order (rt_trace_dev.h).  With one-wave workgroups the
-// 1080p frame measured 1.163 ms at 0 (hardware order), 1.153 at 32, 1.139 at 64, 1.142 at 128, 1.158 at 256,
-// 1.171 at 512: each XCD's L2 then holds the tree under 64 consecutive waves' texels instead of every eighth wave's.
-int rt_xcd_chunk()
+// Defaults of rt_hip_tuning (include/rt_hip.h) with the RT_HIP_* environment overrides, read once per context
+// at rt_hip_create.  xcd_chunk: with one-wave workgroups the 1080p frame measured 1.163 ms at 0 (hardware order),
+// 1.153 at 32, 1.139 at 64, 1.142 at 128, 1.158 at 256, 1.171 at 512: each XCD's L2 then holds the tree under 64
+// consecutive waves' texels instead of every eighth wave's.
+void rt_default_tuning(rt_hip_tuning* t)
 {
-	static int v = -1;
-	if (v < 0) { const char* e = getenv("RT_HIP_XCD_CHUNK"); v = e ? std::max(0, atoi(e)) : 64; }
-	return v;
+	memset(t, 0, sizeof(*t));
+	t->lds_stack_depth = env_int("RT_HIP_LDS_DEPTH", 16);
+	t->xcd_chunk = env_int("RT_HIP_XCD_CHUNK", 64);
+	t->trace_oversub = env_int("RT_HIP_OVERSUB", 4);
+	t->auto_accel = env_int("RT_HIP_AUTO_PLOC", 1) ? RT_HIP_ACCEL_PLOC : RT_HIP_ACCEL_LBVH;
+	t->ploc_radius = env_int("RT_HIP_PLOC_RADIUS", 8);
+	t->frame_sync = env_int("RT_HIP_FRAME_SYNC", 0);
+	t->gather_heavy = 1024;
+	if (const char* e = getenv("RT_HIP_GATHER_HEAVY")) t->gather_heavy = (uint32_t)strtoul(e, nullptr, 10);
+	t->extra_lds_bytes = env_int("RT_HIP_EXTRA_LDS", 0);
+	t->max_bvh_depth = 95;
+	t->refit_max_growth = 2.0f;
+	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
 }
 
-bool rt_auto_ploc()
+void rt_clamp_tuning(rt_hip_ctx* ctx)
 {
-	static int v = -1;
-	if (v < 0) { const char* e = getenv("RT_HIP_AUTO_PLOC"); v = e ? atoi(e) : 1; }
-	return v != 0;
-}
-
-// RT_HIP_OVERSUB (1..16, default RT_TRACE_OVERSUB): grid cap of the trace kernels in units of the resident threads
-static int rt_trace_oversub()
-{
-	if (const char* e = getenv("RT_HIP_OVERSUB")) return std::min(16, std::max(1, atoi(e)));
-	return RT_TRACE_OVERSUB;
-}
-
-int rt_lds_depth()
-{
-	static int v = -1;
-	if (v < 0) { const char* e = getenv("RT_HIP_LDS_DEPTH"); v = e ? atoi(e) : 16; if (v < 1) v = 1; }
-	return v;
+	rt_hip_tuning& t = ctx->tuning;
+	t.lds_stack_depth = std::min(32, std::max(1, t.lds_stack_depth));
+	t.trace_oversub = std::min(16, std::max(1, t.trace_oversub));
+	ctx->max_trace_threads = t.trace_oversub * ctx->resident_threads;
+	// the XCD-aware renumbering needs grids that are multiples of 8 * chunk blocks: keep one such unit of the largest
+	// trace workgroup (256 threads) inside the grid cap, which is also the number of columns of the overflow stack
+	t.xcd_chunk = std::min(std::max(0, t.xcd_chunk), std::max(1, ctx->max_trace_threads / (8 * 256)));
+	if (t.auto_accel != RT_HIP_ACCEL_LBVH) t.auto_accel = RT_HIP_ACCEL_PLOC;
+	t.ploc_radius = std::min(64, std::max(1, t.ploc_radius));
+	t.frame_sync = t.frame_sync ? 1 : 0;
+	t.extra_lds_bytes = std::min(64 * 1024, std::max(0, t.extra_lds_bytes));
+	t.max_bvh_depth = std::min(95, std::max(1, t.max_bvh_depth));
+	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;
 }
 
 int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block)
 {
 	int64_t need = (work_items + block - 1) / block;
 	// a multiple of 8 * xcd_chunk, so that the XCD-aware renumbering of the blocks is a bijection
-	const int64_t unit = 8 * std::max(1, rt_xcd_chunk());
-	int64_t cap = std::max<int64_t>(unit, (int64_t)ctx->max_trace_threads / block / unit * unit);
+	const int64_t unit = 8 * std::max(1, ctx->tuning.xcd_chunk);
+	// never more threads than the overflow stack has columns (rt_clamp_tuning keeps one unit of 256-thread blocks below it)
+	int64_t cap = (int64_t)ctx->max_trace_threads / block / unit * unit;
+	if (cap < unit) cap = std::max<int64_t>(1, (int64_t)ctx->max_trace_threads / block);
 	need = std::max<int64_t>(need, 1);
 	// Above the cap every thread loops; size the grid so that all threads make the SAME number of rounds
 	// (measured on the 1080p frame: a grid that leaves a third of the threads one ray more than the rest is
@@ -123,7 +131,7 @@ int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block)
 
 size_t rt_trace_lds(const SceneView& sv, int block)
 {
-	return sv.use_bvh ? (size_t)sv.lds_depth * block * sizeof(int) + rt_debug_extra_lds() : 0;
+	return sv.use_bvh ? (size_t)sv.lds_depth * block * sizeof(int) + (size_t)sv.extra_lds : 0;
 }
 
 SceneView rt_scene_view(const rt_hip_ctx* ctx)
@@ -146,10 +154,11 @@ SceneView rt_scene_view(const rt_hip_ctx* ctx)
 	sv.num_lights = (int)ctx->lights.size();
 	sv.use_bvh = ctx->use_bvh;
 	sv.stack_depth = ctx->bvh_depth + 1;
-	sv.lds_depth = std::min(sv.stack_depth, rt_lds_depth());
+	sv.lds_depth = std::min(sv.stack_depth, ctx->tuning.lds_stack_depth);
 	sv.spill = ctx->d_spill.as<int>();
 	sv.spill_stride = ctx->max_trace_threads;
-	sv.xcd_chunk = rt_xcd_chunk();
+	sv.xcd_chunk = ctx->tuning.xcd_chunk;
+	sv.extra_lds = ctx->tuning.extra_lds_bytes;
 	sv.tp.eps_det = ctx->cfg.eps_det;
 	sv.tp.eps_t = ctx->cfg.eps_t;
 	sv.tp.t_max = ctx->cfg.t_max;
@@ -317,8 +326,10 @@ int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out)
 	{
 		hipDeviceProp_t prop;
 		if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
-			ctx->max_trace_threads = rt_trace_oversub() * prop.multiProcessorCount * prop.maxThreadsPerMultiProcessor;
-		if (ctx->max_trace_threads <= 0) ctx->max_trace_threads = rt_trace_oversub() * 256 * 2048;
+			ctx->resident_threads = prop.multiProcessorCount * prop.maxThreadsPerMultiProcessor;
+		if (ctx->resident_threads <= 0) ctx->resident_threads = 256 * 2048;
+		rt_default_tuning(&ctx->tuning);
+		rt_clamp_tuning(ctx);
 	}
 	// Non-blocking: no implicit ordering against the legacy default stream (a blocking stream measured
 	// 4 % slower per frame here).  Callers order their own streams against rt_hip_stream() explicitly;
@@ -349,7 +360,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
 	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list, &ctx->d_all_tiles,
-	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_fcount};
+	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_fcount, &ctx->d_leaf_order};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);
@@ -384,6 +395,42 @@ int rt_hip_set_config(rt_hip_ctx* ctx, const rt_hip_config* cfg)
 	return RT_HIP_OK;
 }
 
+int rt_hip_get_tuning(rt_hip_ctx* ctx, rt_hip_tuning* out)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (!out) { rt_set_error("null output"); return RT_HIP_ERR_ARG; }
+	*out = ctx->tuning;
+	return RT_HIP_OK;
+}
+
+int rt_hip_set_tuning(rt_hip_ctx* ctx, const rt_hip_tuning* tuning)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (!tuning) { rt_set_error("null tuning"); return RT_HIP_ERR_ARG; }
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	const rt_hip_tuning old = ctx->tuning;
+	ctx->tuning = *tuning;
+	rt_clamp_tuning(ctx);
+	const rt_hip_tuning& t = ctx->tuning;
+	// what the built structure depends on: rebuild at the next update
+	if (t.auto_accel != old.auto_accel || t.ploc_radius != old.ploc_radius || t.max_bvh_depth != old.max_bvh_depth) {
+		ctx->dirty_topology = true;
+		ctx->scene_dirty = true;
+	}
+	// the HBM part of the traversal stacks follows the LDS depth and the grid cap
+	if (!ctx->scene_dirty && ctx->use_bvh) RT_CHECK(rt_reserve_spill(ctx));
+	return RT_HIP_OK;
+}
+
+int rt_hip_invalidate(rt_hip_ctx* ctx)
+{
+	RT_CHECK(check_ctx(ctx));
+	ctx->dirty_topology = true;
+	ctx->dirty_tables = true;
+	ctx->scene_dirty = true;
+	return RT_HIP_OK;
+}
+
 // ---- scene ---------------------------------------------------------------------------------
 int rt_hip_set_materials(rt_hip_ctx* ctx, const rt_material* materials, int n)
 {
@@ -391,6 +438,7 @@ int rt_hip_set_materials(rt_hip_ctx* ctx, const rt_material* materials, int n)
 	if (n < 0 || (n > 0 && !materials)) { rt_set_error("bad material table"); return RT_HIP_ERR_ARG; }
 	ctx->materials.assign(materials, materials + n);
 	ctx->textures.clear();  // a texture belongs to its Material object (data/data.h:25): new table, no textures
+	ctx->dirty_tables = true;
 	ctx->scene_dirty = true;
 	return RT_HIP_OK;
 }
@@ -408,6 +456,7 @@ int rt_hip_set_texture(rt_hip_ctx* ctx, int material_id, const uint8_t* rgba, in
 		t.texels.resize((size_t)width * height);
 		memcpy(t.texels.data(), rgba, (size_t)width * height * 4);
 	}
+	ctx->dirty_tables = true;
 	ctx->scene_dirty = true;
 	return RT_HIP_OK;
 }
@@ -426,6 +475,7 @@ int rt_hip_set_lights(rt_hip_ctx* ctx, const rt_light* lights, int n)
 	RT_CHECK(check_ctx(ctx));
 	if (n < 0 || (n > 0 && !lights)) { rt_set_error("bad light table"); return RT_HIP_ERR_ARG; }
 	ctx->lights.assign(lights, lights + n);
+	ctx->dirty_tables = true;
 	ctx->scene_dirty = true;
 	return RT_HIP_OK;
 }
@@ -445,6 +495,7 @@ int rt_hip_add_sphere(rt_hip_ctx* ctx, float x, float y, float z, float radius)
 	s.diffuse[1] = (float)(rand() % 256);
 	s.diffuse[0] = (float)(rand() % 256);
 	ctx->spheres.push_back(s);
+	ctx->dirty_topology = true;
 	ctx->scene_dirty = true;
 	return (int)ctx->spheres.size() - 1;
 }
@@ -477,6 +528,7 @@ int rt_hip_add_mesh(rt_hip_ctx* ctx, const float* verts, const float* normals, c
 		int s = rt_hip_add_sphere(ctx, m.position[0], m.position[1], m.position[2], 1.0f);
 		if (s < 0) return s;
 	}
+	ctx->dirty_topology = true;
 	ctx->scene_dirty = true;
 	return (int)ctx->meshes.size() - 1;
 }
@@ -485,7 +537,13 @@ int rt_hip_set_model_mat(rt_hip_ctx* ctx, int mesh_id, const float* model_mat16)
 {
 	RT_CHECK(check_ctx(ctx));
 	if (mesh_id < 0 || mesh_id >= (int)ctx->meshes.size() || !model_mat16) { rt_set_error("bad mesh id"); return RT_HIP_ERR_ARG; }
+	// Change detection: the reference's processRays re-reads every Mesh::model_mat each frame (rt_raytracer.cpp:467);
+	// a matrix equal to the one in use changes nothing, and without use_model_mat (AccelArray semantics,
+	// rt_accel_array.cpp:17-32) the geometry does not depend on it at all.
+	if (memcmp(ctx->meshes[mesh_id].model, model_mat16, sizeof(float) * 16) == 0) return RT_HIP_OK;
 	memcpy(ctx->meshes[mesh_id].model, model_mat16, sizeof(float) * 16);
+	if (!ctx->cfg.use_model_mat || ctx->cfg.geometry != RT_HIP_TRIANGLES) return RT_HIP_OK;
+	ctx->dirty_xf = true;
 	ctx->scene_dirty = true;
 	return RT_HIP_OK;
 }
@@ -499,8 +557,9 @@ int rt_hip_update(rt_hip_ctx* ctx)
 			rt_set_error("mesh material id %d outside the material table (%zu)", m.material, ctx->materials.size());
 			return RT_HIP_ERR_ARG;
 		}
+	if (!ctx->scene_dirty) { ctx->stats.last_update = RT_HIP_UPDATE_NONE; return RT_HIP_OK; }
 	RT_CHECK(rt_build_geometry(ctx));
-	ctx->scene_dirty = false;
+	ctx->scene_dirty = ctx->dirty_topology = ctx->dirty_tables = ctx->dirty_xf = false;
 	return RT_HIP_OK;
 }
 
@@ -866,6 +925,28 @@ int rt_hip_radiance_estimate(rt_hip_ctx* ctx, const float* pos, const float* nrm
 	return RT_HIP_OK;
 }
 
+int rt_hip_photon_lookup_device(rt_hip_ctx* ctx, const float* d_pos, int npts, float radius, float* d_rgb_out)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (npts < 0 || !(radius > 0.0f) || (npts > 0 && (!d_pos || !d_rgb_out))) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	return rt_photon_lookup(ctx, d_pos, npts, radius, d_rgb_out);
+}
+
+int rt_hip_photon_lookup(rt_hip_ctx* ctx, const float* pos, int npts, float radius, float* rgb_out)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (npts < 0 || (npts > 0 && (!pos || !rgb_out))) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	if (npts == 0) return RT_HIP_OK;
+	hipStream_t st = ctx->stream;
+	RT_CHECK(ctx->d_org.reserve((size_t)npts * 12));
+	RT_CHECK(ctx->d_accum.reserve((size_t)npts * 12));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_org.p, pos, (size_t)npts * 12, hipMemcpyHostToDevice, st));
+	RT_CHECK(rt_hip_photon_lookup_device(ctx, ctx->d_org.as<float>(), npts, radius, ctx->d_accum.as<float>()));
+	RT_HIP_CHECK(hipMemcpyAsync(rgb_out, ctx->d_accum.p, (size_t)npts * 12, hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	return RT_HIP_OK;
+}
+
 // ---- the live (Gen-2) frame ---------------------------------------------------------------------------
 int rt_hip_live_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
                              int height, int interlace, int phase, uint8_t* d_raypass_rgb8, uint8_t* d_rgba_out,
@@ -984,7 +1065,11 @@ int rt_hip_reset_stats(rt_hip_ctx* ctx)
 	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	RT_CHECK(rt_collect_timing(ctx));
 	double build = ctx->stats.build_ms;
+	const int last_update = ctx->stats.last_update;
 	memset(&ctx->stats, 0, sizeof(ctx->stats));
+	ctx->stats.last_update = last_update;
+	ctx->stats.bvh_area_cost = ctx->use_bvh ? ctx->bvh_cost_now : 0.0;
+	ctx->stats.bvh_area_cost_built = ctx->use_bvh ? ctx->bvh_cost_built : 0.0;
 	if (ctx->d_census.p) RT_HIP_CHECK(hipMemset(ctx->d_census.p, 0, 64));
 	ctx->stats.build_ms = build;
 	ctx->stats.num_tris = ctx->num_tris;

@@ -82,6 +82,7 @@ struct SceneView {
 	int* spill;       // [stack_depth - lds_depth][spill_stride] ints in HBM (nullptr if not needed)
 	int spill_stride; // = maximum number of threads of a trace launch
 	int xcd_chunk;    // XCD-aware block renumbering (rt_trace_dev.h); 0 = hardware order
+	int extra_lds;    // host side only: tuning.extra_lds_bytes
 	TraceParams tp;
 };
 
@@ -104,6 +105,7 @@ struct FrameSet {
 
 struct rt_hip_ctx {
 	rt_hip_config cfg;
+	rt_hip_tuning tuning;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;  // pending (profile mode)
@@ -112,11 +114,12 @@ struct rt_hip_ctx {
 	DevBuf d_census, d_spill, d_tile_list;
 	int tile_key[5] = {0, 0, 0, 0, 0};                            // (w, h, tile, rank, nranks) of d_tile_list
 	int tile_count = 0;
-	bool warned_fallback = false;
+	bool warned_fallback = false, warned_depth = false;
 	DevBuf d_all_tiles;                                           // every rank's tile list, concatenated (unpack of a received step)
 	int all_tiles_key[4] = {0, 0, 0, 0};                          // (w, h, tile, nranks)
 	int all_tiles_offset[RT_MAX_BATCH + 1] = {};
-	int max_trace_threads = 0;  // grid cap of the trace kernels = RT_TRACE_OVERSUB x resident-thread capacity
+	int resident_threads = 0;   // CUs x threads per CU
+	int max_trace_threads = 0;  // grid cap of the trace kernels = tuning.trace_oversub x resident_threads
 
 	std::vector<HostMesh> meshes;
 	std::vector<HostSphere> spheres;
@@ -126,8 +129,15 @@ struct rt_hip_ctx {
 	const float* frame_uv[RT_MAX_BATCH] = {};                     // rt_hip_set_frame_texcoords_device
 	int frame_uv_count = 0;
 	std::vector<rt_light> lights;
+	// What changed since the last rt_hip_update.  scene_dirty = any of them (tracing is refused until the update).
 	bool scene_dirty = true;
+	bool dirty_topology = true;   // meshes / spheres added, first update, rt_hip_invalidate: everything from scratch
+	bool dirty_tables = true;     // materials, lights, textures
+	bool dirty_xf = false;        // a model matrix changed (and the context applies model matrices)
 	bool sphere_rng_seeded = false;
+	float bvh_cost_now = 0.0f;    // the same for the boxes in use (differs from bvh_cost_built after a refit)
+	float bvh_cost_built = 0.0f;  // sum of node half-areas / root half-area at the last build (refit quality check)
+	DevBuf d_leaf_order;          // leaf slot -> global triangle id of the BVH in use (kept for refits; d_order is scratch)
 
 	// geometry in HBM
 	DevBuf d_verts, d_normals, d_texcoords, d_faces, d_mesh_of_tri, d_mesh_xf;  // inputs of the soup kernel
@@ -160,15 +170,12 @@ struct rt_hip_ctx {
 };
 
 SceneView rt_scene_view(const rt_hip_ctx* ctx);
-size_t rt_debug_extra_lds();
-bool rt_auto_ploc();           // RT_HIP_AUTO_PLOC: what ACCEL_AUTO builds
-int rt_xcd_chunk();            // RT_HIP_XCD_CHUNK
-int rt_lds_depth();           // RT_HIP_LDS_DEPTH, default 16
-constexpr int RT_TRACE_OVERSUB = 4;
+void rt_default_tuning(rt_hip_tuning* t);   // defaults, then the RT_HIP_* environment overrides
+void rt_clamp_tuning(rt_hip_ctx* ctx);      // ranges; also derives max_trace_threads
 // Launch shape of the trace kernels: blocks of `block` threads, at most ctx->max_trace_threads in
 // total (the spill stack has exactly that many columns).
 int rt_trace_blocks(const rt_hip_ctx* ctx, int64_t work_items, int block);
-size_t rt_trace_lds(const SceneView& sv, int block);  // RT_HIP_EXTRA_LDS (bytes): occupancy experiments only
+size_t rt_trace_lds(const SceneView& sv, int block);
 int rt_begin_trace_timing(rt_hip_ctx* ctx, hipStream_t st = nullptr);  // nullptr: ctx->stream
 int rt_end_trace_timing(rt_hip_ctx* ctx, int cls, hipStream_t st = nullptr);
 int rt_next_trace_events(rt_hip_ctx* ctx, int cls, hipEvent_t* a, hipEvent_t* b);  // for hipExtLaunchKernelGGL
@@ -177,10 +184,13 @@ int rt_collect_timing(rt_hip_ctx* ctx);
 int rt_ensure_pinned(void** p, size_t* cap, size_t bytes);
 
 // ---- k_geometry.hip ------------------------------------------------------------------------------
-int rt_build_geometry(rt_hip_ctx* ctx);  // soup + (optional) LBVH, all on ctx->stream
+int rt_build_geometry(rt_hip_ctx* ctx);  // what the dirty flags ask for: tables, soup + refit, or soup + build; all on ctx->stream
 
 // ---- k_lbvh.hip ----------------------------------------------------------------------------------
 int rt_build_lbvh(rt_hip_ctx* ctx);
+// Boxes of the kept topology from the current tri_box / d_isect_src (original order); *cost = area sum / root area.
+int rt_refit_lbvh(rt_hip_ctx* ctx, const TriIsect* d_isect_src, float* cost);
+int rt_reserve_spill(rt_hip_ctx* ctx);  // HBM part of the traversal stacks for the current depth / tuning
 
 // ---- k_trace.hip ---------------------------------------------------------------------------------
 // d_count != nullptr: n is the capacity, the ray count is read on the device (brute force ignores it: BVH only)
@@ -229,6 +239,7 @@ int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count,
 int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n);
 int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int npts, int count, float radius,
                      float* d_rgb);
+int rt_photon_lookup(rt_hip_ctx* ctx, const float* d_pos, int npts, float radius, float* d_rgb);
 
 // ---- shared device-scan / multisplit helpers (k_sort.hip) -----------------------------------------
 // Stable counting-sort pass on an 8-bit digit: out_rank[i] = destination of element i.

@@ -152,7 +152,9 @@ __device__ __forceinline__ bool mt_closest(f3 O, f3 D, f3 v0, f3 e1, f3 e2, uint
 	u *= inv_det;
 	v *= inv_det;
 	if (t < tp.eps_t) return false;
-	if (t < best.t || (t == best.t && prim < best.prim)) {
+	// the tie rule applies between two real hits only: while `best` is still the initial {t_max, RT_MISS}, a hit at
+	// exactly t == t_max is rejected as the reference rejects it (t < min_t, rt_accel_array.cpp:116)
+	if (t < best.t || (t == best.t && best.prim != RT_MISS && prim < best.prim)) {
 		best.t = t; best.u = u; best.v = v; best.prim = prim;
 		return true;
 	}

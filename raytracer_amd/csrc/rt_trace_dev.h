@@ -34,7 +34,7 @@ __device__ __forceinline__ int stack_pop(const SceneView& sv, const lds_int* sta
 }
 
 // ---- launch shape of the trace kernels ----------------------------------------------------------
-// Grid-stride loops over a grid capped at RT_TRACE_OVERSUB x the device's resident-thread capacity.
+// Grid-stride loops over a grid capped at tuning.trace_oversub (4) x the device's resident-thread capacity.
 // The cap bounds the spill stack (one column per launched thread); the oversubscription leaves the
 // balancing of uneven rays to the hardware dispatcher.  Measured on MI355X (atrium-262k, shadow
 // rays): 1x 0.765 ms, 2x 0.657 ms, 4x 0.586 ms, uncapped 0.594 ms; a software queue (one returning

@@ -89,16 +89,17 @@ def test_c3_any_hit_is_closest_hit_below_tmax(rt, torch, c3):
     assert float((occ > 0).float().mean()) > 0.05
 
 
-def test_c3_frame_drivers_agree_and_repeat(rt, torch, c3, monkeypatch):
+def test_c3_frame_drivers_agree_and_repeat(rt, torch, c3):
     """The sync-free driver (levels sized by bounds) and the host-sized one render the same 1080p image, ray for
     ray; rendering again changes nothing."""
     g = c3["g"]
     again = torch.zeros_like(c3["frame"])
     g.render_frame_device(c3["d_p"], c3["d_n"], W, H, again)
     assert torch.equal(again, c3["frame"]) and g.last_frame_rays() == c3["rays"]
-    monkeypatch.setenv("RT_HIP_FRAME_SYNC", "1")
+    g.set_tuning(frame_sync=1)
     sync = torch.zeros_like(c3["frame"])
     g.render_frame_device(c3["d_p"], c3["d_n"], W, H, sync)
+    g.set_tuning(frame_sync=0)
     assert torch.equal(sync, c3["frame"]) and g.last_frame_rays() == c3["rays"]
     assert c3["rays"] > 10_000_000
     assert int(c3["frame"].view(-1, 4)[:, :3].max()) > 60
@@ -170,7 +171,7 @@ def test_c4_bvh_equals_exhaustive_search_1m(rt, torch):
     assert_bits_equal(x["hits"]["t"][hit], y["hits"]["t"][hit], "t")
 
 
-def test_c5_gather_kernels_agree_at_10m_photons(rt, torch, c3, monkeypatch):
+def test_c5_gather_kernels_agree_at_10m_photons(rt, torch, c3):
     """C5's photon map (10 M emitted): the per-lane and the per-wave gather give the same radiance at 30 k points
     of the frame (2e-5 relative: the order of the float sum differs), NaN exactly where no photon is in range, and
     the sharded emission concatenates to the same photon set."""
@@ -194,8 +195,8 @@ def test_c5_gather_kernels_agree_at_10m_photons(rt, torch, c3, monkeypatch):
     pos, _ = _sample_rays(torch, c3, 30_000, 9)
     nrm = torch.zeros_like(pos); nrm[:, 1] = 1.0
     outs = {}
-    for name, heavy in (("lane", "4000000000"), ("wave", "0"), ("split", "1024")):
-        monkeypatch.setenv("RT_HIP_GATHER_HEAVY", heavy)
+    for name, heavy in (("lane", 4000000000), ("wave", 0), ("split", 1024)):
+        g.set_tuning(gather_heavy=heavy)
         out = torch.zeros_like(pos)
         g.radiance_estimate_device(pos, nrm, pos.shape[0], 100, 1.0, out)
         outs[name] = out.cpu().numpy()

@@ -55,14 +55,12 @@ def test_emission_is_shard_invariant(oracle_cls):
     g.close()
 
 
-@pytest.mark.parametrize("heavy", [None, "0", "4000000000"], ids=["default-split", "all-wave", "all-lane"])
+@pytest.mark.parametrize("heavy", [None, 0, 4000000000], ids=["default-split", "all-wave", "all-lane"])
 @pytest.mark.parametrize("count,radius", [(100, 1.0), (50, 3.0), (7, 0.5)])
-def test_gather_matches_oracle(oracle_cls, count, radius, heavy, monkeypatch):
+def test_gather_matches_oracle(oracle_cls, count, radius, heavy):
     """Both gather kernels against the oracle: by default a point goes to the wave-per-point kernel when its
-    cube holds more than 1024 photons; RT_HIP_GATHER_HEAVY = 0 / huge sends every point one way."""
+    cube holds more than 1024 photons; tuning.gather_heavy = 0 / huge sends every point one way."""
     import raytracer_amd as rt
-    if heavy is not None:
-        monkeypatch.setenv("RT_HIP_GATHER_HEAVY", heavy)
     sc = scenes.cornell()
     orc = oracle_cls(sc)
     ph = orc.photon_generate(6000, geometry=0, rng=1, seed=42)
@@ -71,6 +69,9 @@ def test_gather_matches_oracle(oracle_cls, count, radius, heavy, monkeypatch):
     orc.photon_set(ph)
     exp = orc.radiance_estimate(pos, nrm, count, radius)
     g = rt.RtHip(sc, semantics="array", photon_radius=radius)
+    if heavy is not None:
+        g.set_tuning(gather_heavy=heavy)
+        assert g.tuning()["gather_heavy"] == heavy
     g.photon_set(ph)
     got = g.radiance_estimate(pos, nrm, count, radius)
     np.testing.assert_array_equal(np.isnan(exp), np.isnan(got))   # the empty-neighbourhood NaN (rt_photon_map.cpp:204)
@@ -85,13 +86,12 @@ def test_gather_matches_oracle(oracle_cls, count, radius, heavy, monkeypatch):
     g.close()
 
 
-@pytest.mark.parametrize("heavy", ["0", "4000000000"], ids=["all-wave", "all-lane"])
-def test_gather_ties_at_the_kth_distance(oracle_cls, heavy, monkeypatch):
+@pytest.mark.parametrize("heavy", [0, 4000000000], ids=["all-wave", "all-lane"])
+def test_gather_ties_at_the_kth_distance(oracle_cls, heavy):
     """Every photon stored three times: the k-th distance is shared by photons of which only some may be taken
     (k = 100 is not a multiple of 3).  The copies are identical, so whichever the reference's unstable sort keeps,
     the sum is the same; both kernels must take exactly k."""
     import raytracer_amd as rt
-    monkeypatch.setenv("RT_HIP_GATHER_HEAVY", heavy)
     sc = scenes.cornell()
     orc = oracle_cls(sc)
     ph = np.repeat(orc.photon_generate(3000, geometry=0, rng=1, seed=5), 3, axis=0)
@@ -99,7 +99,7 @@ def test_gather_ties_at_the_kth_distance(oracle_cls, heavy, monkeypatch):
     pos, nrm, _ = orc.gbuffer_select(nr, po)
     orc.photon_set(ph)
     exp = orc.radiance_estimate(pos, nrm, 100, 1.5)
-    g = rt.RtHip(sc, semantics="array", photon_radius=1.5)
+    g = rt.RtHip(sc, semantics="array", photon_radius=1.5, tuning=dict(gather_heavy=heavy))
     g.photon_set(ph)
     got = g.radiance_estimate(pos, nrm, 100, 1.5)
     ok = ~np.isnan(exp)
@@ -173,4 +173,35 @@ def test_c5_pipeline_single_rank(oracle_cls):
     ok = np.isfinite(a).all(1)
     np.testing.assert_array_equal(np.isfinite(b).all(1), ok)
     np.testing.assert_allclose(b[ok], a[ok], rtol=1e-5, atol=1e-9)
+    g.close()
+
+
+def test_lookup_vs_reference_vectors(oracle_cls):
+    """PhotonMap::lookup (rt_photon_map.cpp:126-142) against the compiled reference's outputs in
+    tests/golden/photons_cornell.npz (`lookup_r1`) and against the oracle at another radius.  The GPU sums the
+    energies in grid order, the reference in photon order: rtol 2e-5 (the same bar as radiance_estimate); points
+    with no photon in range are exactly zero on both sides."""
+    import raytracer_amd as rt
+    from test_oracle_golden import load, scene_for
+    gold = load("photons_cornell")
+    sc = scene_for("cornell", gold)
+    g = rt.RtHip(sc, semantics="array", photon_radius=1.0)
+    zero = g.photon_lookup(gold["pos"], 1.0)             # no photon map yet: the empty sum
+    assert not zero.any()
+    g.photon_set(gold["photons"])
+    got = g.photon_lookup(gold["pos"], 1.0)
+    exp = gold["lookup_r1"]
+    assert (exp.sum(1) > 0).mean() > 0.3
+    np.testing.assert_array_equal(got == 0, exp == 0)
+    np.testing.assert_allclose(got, exp, rtol=2e-5, atol=1e-9)
+    orc = oracle_cls(sc)
+    orc.photon_set(gold["photons"])
+    for radius in (0.35, 2.5):                           # below and above the grid cell the photons were binned with
+        np.testing.assert_allclose(g.photon_lookup(gold["pos"], radius), orc.photon_lookup(gold["pos"], radius), rtol=2e-5, atol=1e-9)
+    # the device-pointer entry
+    torch = _torch()
+    d_pos = torch.from_numpy(np.ascontiguousarray(gold["pos"], np.float32)).cuda()
+    d_out = torch.zeros_like(d_pos)
+    g.photon_lookup_device(d_pos, d_pos.shape[0], 1.0, d_out)
+    np.testing.assert_array_equal(d_out.cpu().numpy(), got)
     g.close()

@@ -17,6 +17,7 @@ SCENES = {
     "cornell": scenes.cornell,
     "atrium2k": lambda: scenes.atrium(2048),
     "atrium2k_xf": lambda: scenes.with_transforms(scenes.atrium(2048)),
+    "atrium8k": lambda: scenes.atrium(8192),
     "spheres": scenes.sphere_field,
 }
 
@@ -42,7 +43,7 @@ def groups(offset_material, offset_end, records):
     return out
 
 
-@pytest.mark.parametrize("name", ["cornell", "atrium2k", "atrium2k_xf"])
+@pytest.mark.parametrize("name", ["cornell", "atrium2k", "atrium2k_xf", "atrium8k"])
 def test_process_rays_golden(oracle_cls, name):
     g = load("process_" + name)
     sc = scene_for(name, g)
@@ -64,7 +65,7 @@ def test_process_rays_golden(oracle_cls, name):
             assert_bits_equal(ga[m]["normal"], gb[m]["normal"], "normal material %d" % m)
 
 
-@pytest.mark.parametrize("name", ["cornell", "atrium2k"])
+@pytest.mark.parametrize("name", ["cornell", "atrium2k", "atrium8k"])
 def test_array_golden(oracle_cls, name):
     g = load("array_" + name)
     sc = scene_for(name, g)

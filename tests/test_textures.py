@@ -94,12 +94,11 @@ def test_gbuffer_uv(rt, oracle_cls):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shadows,bounces,stmax", [(0, 3, 0.0), (1, 3, 1.0)], ids=["noshadow-b3", "shadowfix-b3"])
 @pytest.mark.parametrize("path", ["async", "sync"])
-def test_textured_frame(rt, oracle_cls, shadows, bounces, stmax, path, monkeypatch):
+def test_textured_frame(rt, oracle_cls, shadows, bounces, stmax, path):
     """shade() with textured materials at every level of the tree (level 0 from the G-buffer's texcoord
     plane, deeper levels from the hit's interpolated texcoord), both frame drivers.  Tolerance as the
     untextured frame: max-abs 1 per channel."""
     torch = _torch()
-    monkeypatch.setenv("RT_HIP_FRAME_SYNC", "1" if path == "sync" else "0")
     sc = textured_cornell()
     orc = oracle_cls(sc)
     w, h = 100, 75
@@ -111,7 +110,7 @@ def test_textured_frame(rt, oracle_cls, shadows, bounces, stmax, path, monkeypat
     exp0, _, _ = orc.render_texels(po, nrm, mid, **kw)             # level-0 texcoords (0, 0)
     plain, _, _ = oracle_cls(scenes.cornell()).render_texels(po, nrm, mid, **kw)
     assert (exp != plain).any(1).mean() > 0.3 and (exp != exp0).any(1).mean() > 0.1   # the textures matter
-    g = rt.RtHip(sc, semantics="array", **kw)
+    g = rt.RtHip(sc, semantics="array", tuning=dict(frame_sync=1 if path == "sync" else 0), **kw)
     d_uv = torch.from_numpy(uv).cuda()
     g.set_frame_texcoords_device([d_uv])
     got = g.render_frame(po, nr, w, h)
