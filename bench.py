@@ -500,48 +500,48 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
     cfg["ms_per_frame_host_to_host"] = round(float(np.median(ts)), 3)
     cfg["host_to_host_note"] = ("rt_hip_render_frame: %.1f MB G-buffer up with hipMemcpyAsync from pinned host memory, frame, %.1f MB image down; "
                                 "median of 20; PCIe-bound, never `value`" % (npix * 28 / 1e6, npix * 4 / 1e6))
-    # the frame with the scene brought up to date first
-    ident = np.eye(4, dtype=np.float32).reshape(16)
-    moved = ident.copy()
+    # The frame with the scene brought up to date first, on a context that applies model matrices as processRays does
+    # (use_model_mat = 1; the scene's matrices are identities, so the geometry and the image are the same).
     render = type(g).render_tiles_batch_device.__wrapped__
+    g2 = rt.RtHip(scene, semantics="array", accel=ACCEL[args.accel], device=dev_index, profile=0, bounces=2, do_shadows=1,
+                  use_model_mat=1, shadow_t_max=1.0 if args.shadow_mode == "corrected" else 0.0, seed=42)
+    mats = np.stack([np.ascontiguousarray(me.model_colmajor(), dtype=np.float32).reshape(16) for me in scene.meshes])
+    kinds = {}
 
-    def frame_after(prepare, n=20):
+    def frame_after(prepare, label, n=20):
         ts = []
         for i in range(n + 3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             prepare(i)
-            g.update()
-            render(g, [gb_p], [gb_n], W, H, 64, 0, 1, [out_dev])
-            g.sync()
+            g2.update()
+            render(g2, [gb_p], [gb_n], W, H, 64, 0, 1, [out_dev])
+            g2.sync()
             if i >= 3:
                 ts.append((time.perf_counter() - t0) * 1e3)
+        kinds[label] = ["none", "tables", "refit", "rebuild"][g2.stats()["last_update"]]
         return round(float(np.median(ts)), 3)
 
-    nm = len(scene.meshes)
-    mats = [np.ascontiguousarray(me.model_colmajor(), dtype=np.float32).reshape(16) for me in scene.meshes]
-
     def same(i):
-        for m in range(nm):
-            g.set_model_mat(m, mats[m])
+        g2.set_model_mats(0, mats)
 
-    def jitter(i):   # every mesh moved a little and back: new boxes, same topology
-        for m in range(nm):
-            mm = mats[m].copy()
-            mm[12] += 1e-3 * (1 + (i & 1))
-            g.set_model_mat(m, mm)
+    def jitter(i):   # every mesh moved a little, differently each frame: new boxes, same topology
+        mm = mats.copy()
+        mm[:, 12] += 1e-3 * (1 + (i & 1))
+        g2.set_model_mats(0, mm)
 
-    cfg["ms_per_frame_with_update_unchanged"] = frame_after(same)
-    cfg["ms_per_frame_with_update_moved"] = frame_after(jitter)
-    same(0)
-    if hasattr(g, "force_rebuild"):
-        cfg["ms_per_frame_with_rebuild"] = frame_after(lambda i: g.force_rebuild())
-    else:
-        cfg["ms_per_frame_with_rebuild"] = cfg["ms_per_frame_with_update_moved"]
-    same(0)
-    g.update()
-    cfg["with_update_note"] = ("set every Mesh::model_mat + rt_hip_update + the device-resident frame, median of 20 (what processRays' per-call soup "
-                               "rebuild, rt_raytracer.cpp:457-503, costs here): unchanged matrices, matrices moved, full rebuild forced")
+    def rebuild(i):
+        jitter(i)
+        g2.invalidate()
+
+    cfg["ms_per_frame_with_update_unchanged"] = frame_after(same, "unchanged")
+    cfg["ms_per_frame_with_update_moved"] = frame_after(jitter, "moved")
+    cfg["ms_per_frame_with_rebuild"] = frame_after(rebuild, "rebuild")
+    cfg["with_update_kinds"] = kinds
+    g2.close()
+    cfg["with_update_note"] = ("one rt_hip_set_model_mats call for all %d meshes + rt_hip_update + the device-resident frame, host clock, median of 20 "
+                               "(the slot of processRays' per-call soup rebuild, rt_raytracer.cpp:457-503): matrices unchanged (update finds "
+                               "nothing to do), every matrix moved (soup + refit on the kept topology), build from scratch forced" % len(scene.meshes))
     # literal reference shadows on the same frame
     if args.shadow_mode == "corrected":
         g.set_config(shadow_t_max=0.0)

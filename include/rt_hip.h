@@ -215,6 +215,9 @@ int rt_hip_add_mesh(rt_hip_ctx* ctx, const float* verts, const float* normals, c
  * (the reference's own PhotonMap::generate included). */
 int rt_hip_add_sphere(rt_hip_ctx* ctx, float x, float y, float z, float radius);
 int rt_hip_set_model_mat(rt_hip_ctx* ctx, int mesh_id, const float* model_mat16);
+/* The same for meshes [first_mesh, first_mesh + n) in one call: n x 16 floats (what a frame loop does once per
+ * frame, rt_raytracer.cpp:465-467).  Matrices equal to the ones in use change nothing. */
+int rt_hip_set_model_mats(rt_hip_ctx* ctx, int first_mesh, int n, const float* model_mats16);
 /* IAccel::update (rt_iaccel.h:8): bring the device scene up to date.  Must be called after the scene changes
  * and before tracing.  It does the least that the changes since the last update need (rt_hip_update_kind):
  * nothing; the material / light / texture tables only; for changed model matrices (rt_hip_set_model_mat
@@ -388,6 +391,14 @@ int rt_hip_shade_results_device(rt_hip_ctx* ctx, const rt_ray* d_results, const 
  * A photon is stored at most once, so capacity (in photons) must be >= count. */
 int rt_hip_photon_emit_device(rt_hip_ctx* ctx, int photons_per_light, int64_t first, int64_t count,
                               float* d_photons_out, int64_t capacity, int64_t* out_stored);
+/* PhotonMap::generate in one call for host-only callers (no device buffer to manage): photons_per_light photons
+ * per light of the context's light table, emitted with the counter RNG under config.seed, kept in the context and
+ * installed as its photon map (grid built).  *out_stored = photons in the map.  The single-GPU form of
+ * rt_hip_photon_emit_device + rt_hip_photon_set_device. */
+int rt_hip_photon_generate(rt_hip_ctx* ctx, int photons_per_light, int64_t* out_stored);
+/* The installed photon set back on the host, in photon-index order (9 floats each: position, energy, direction),
+ * i.e. PhotonMap::photons; *out_n = how many (capacity in photons must cover them; capacity 0 only asks for the count). */
+int rt_hip_photon_get(rt_hip_ctx* ctx, float* photons_out, int64_t capacity, int64_t* out_n);
 /* Install the (all-gathered) photon set and build the hashed grid (cell = radius). */
 int rt_hip_photon_set_device(rt_hip_ctx* ctx, const float* d_photons, int64_t n);
 int rt_hip_photon_set(rt_hip_ctx* ctx, const float* photons, int64_t n);

@@ -420,6 +420,43 @@ int dropin_photon_generate(int count, long long* seed_used)
 	return -1;
 }
 
+// The reference-shaped photon sequence with the GPU photon map in PhotonMap's place: generate once
+// (rt_raytracer.cpp:165-167), then radiance_estimate per shading point (rt_raytracer.cpp:155-157) and lookup.
+// The first `single` points go through the single-point methods with the reference's signatures, the rest
+// through the batch forms.  Returns the number of photons stored (copied to photons_out, 9 floats each).
+long long dropin_photon_map_hip(int count, unsigned long long seed, int npts, const float* pos, const float* nrm,
+                                unsigned int k, float radius, int single, float* out_est, float* out_lookup,
+                                float* photons_out, long long max_photons)
+{
+	if (!g.scene) {
+		g.scene = (Scene*)calloc(1, sizeof(Scene));
+		for (size_t i = 0; i < g.lights.size(); ++i) g.scene->lights.push_back(g.lights[i]);
+	}
+	if (!g_hip) {
+		g_hip = new AccelHip(0, 0);
+		if (!g_hip->ok()) return -2;
+		for (size_t i = 0; i < g.meshes.size(); ++i) g_hip->addMesh(g.meshes[i]);
+	}
+	PhotonMapHip* pm = new PhotonMapHip(seed);
+	pm->generate(g.scene, g_hip, count);
+	const Eigen::Vector3f* P = (const Eigen::Vector3f*)pos;
+	const Eigen::Vector3f* N = (const Eigen::Vector3f*)nrm;
+	Eigen::Vector3f* E = (Eigen::Vector3f*)out_est;
+	Eigen::Vector3f* L = (Eigen::Vector3f*)out_lookup;
+	if (single > npts) single = npts;
+	for (int i = 0; i < single; ++i) {
+		E[i] = pm->radiance_estimate(P[i], Eigen::Vector3f(0, 0, -1), N[i], k, radius);
+		L[i] = pm->lookup(P[i], radius);
+	}
+	pm->radianceEstimateBatch(P + single, N + single, npts - single, k, radius, E + single);
+	pm->lookupBatch(P + single, npts - single, radius, L + single);
+	long long n = pm->photonCount();
+	if (n > max_photons) return -3;
+	if (n > 0 && pm->photons(photons_out, max_photons) != n) return -4;
+	delete pm;
+	return n;
+}
+
 int dropin_process_rays(int count, const float* positions, const float* normals, void* out_records,
                         int* out_offset_material, int* out_offset_end, int* n_materials)
 {

@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device", "rt_hip_gbuffer_select_noalloc_device",
-    "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
+    "rt_hip_set_model_mats", "rt_hip_photon_generate", "rt_hip_photon_get", "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
 ]
 
 
@@ -127,6 +127,7 @@ def load_library() -> C.CDLL:
     L.rt_hip_add_mesh.argtypes = [P, c_float_p, c_float_p, c_float_p, C.c_int, c_u32_p, C.c_int, c_float_p, C.c_int, c_float_p]
     L.rt_hip_add_sphere.argtypes = [P, C.c_float, C.c_float, C.c_float, C.c_float]
     L.rt_hip_set_model_mat.argtypes = [P, C.c_int, c_float_p]
+    L.rt_hip_set_model_mats.argtypes = [P, C.c_int, C.c_int, c_float_p]
     L.rt_hip_update.argtypes = [P]
     L.rt_hip_intersect.argtypes = [P, P, C.c_int, c_u8_p, c_u32_p, P]
     L.rt_hip_occlude.argtypes = [P, P, C.c_int, c_u8_p]
@@ -149,6 +150,8 @@ def load_library() -> C.CDLL:
     L.rt_hip_last_frame_rays.argtypes = [P]
     L.rt_hip_last_frame_rays.restype = C.c_int64
     L.rt_hip_photon_emit_device.argtypes = [P, C.c_int, C.c_int64, C.c_int64, P, C.c_int64, C.POINTER(C.c_int64)]
+    L.rt_hip_photon_generate.argtypes = [P, C.c_int, C.POINTER(C.c_int64)]
+    L.rt_hip_photon_get.argtypes = [P, c_float_p, C.c_int64, C.POINTER(C.c_int64)]
     L.rt_hip_photon_set_device.argtypes = [P, P, C.c_int64]
     L.rt_hip_photon_set.argtypes = [P, c_float_p, C.c_int64]
     L.rt_hip_radiance_estimate_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_float, P]
@@ -329,6 +332,11 @@ class RtHip:
     def force_rebuild(self):
         self.invalidate()
 
+    def set_model_mats(self, first_mesh, mats_colmajor):
+        """Mesh::model_mat of consecutive meshes, (n, 16) column-major; takes effect at the next update()."""
+        m = np.ascontiguousarray(mats_colmajor, dtype=np.float32).reshape(-1, 16)
+        self._ck(self.lib.rt_hip_set_model_mats(self.h, int(first_mesh), m.shape[0], _p(m)))
+
     def set_config(self, **kw):
         for k, v in kw.items():
             setattr(self.cfg, k, v)
@@ -477,6 +485,21 @@ class RtHip:
         stored = C.c_int64(0)
         self._ck(self.lib.rt_hip_photon_emit_device(self.h, per_light, first, count, _dptr(d_out), capacity, C.byref(stored)))
         return stored.value
+
+    def photon_generate(self, per_light):
+        """PhotonMap::generate on one GPU: emit, keep, build the grid; returns the number of photons stored."""
+        stored = C.c_int64(0)
+        self._ck(self.lib.rt_hip_photon_generate(self.h, per_light, C.byref(stored)))
+        return stored.value
+
+    def photon_get(self):
+        """The installed photons in photon-index order, (n, 9) f32."""
+        n = C.c_int64(0)
+        self._ck(self.lib.rt_hip_photon_get(self.h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 9), np.float32)
+        if n.value:
+            self._ck(self.lib.rt_hip_photon_get(self.h, _p(out), n.value, C.byref(n)))
+        return out
 
     def photon_set_device(self, d_photons, n):
         self._ck(self.lib.rt_hip_photon_set_device(self.h, _dptr(d_photons), n))

@@ -90,38 +90,60 @@ struct __attribute__((aligned(64))) BoxSlot {
 static_assert(sizeof(BoxSlot) == 64, "one cache line per subtree box");
 
 // Slots [0, n-1) = internal nodes, [n-1, 2n-1) = leaves.
-__global__ __launch_bounds__(256) void k_refit(const float4* __restrict__ tri_box, const uint32_t* __restrict__ order,
-                                               int n, float pad, const int* __restrict__ left,
-                                               const int* __restrict__ right, const int* __restrict__ node_parent,
-                                               const int* __restrict__ leaf_parent, BoxSlot* slots,
-                                               unsigned int* arrive)
+//
+// Bottom-up boxes, level by level.  A node's children sit one level deeper, so processing the levels from the
+// deepest to the root -- one launch per level over that level's node list -- makes every node read finished child
+// boxes, with the kernel boundary as the only synchronisation.  (The first version walked up from every leaf with an
+// arrival counter per node and an agent-scope release / acquire pair per step: correct, but 1.5 ms for 262k triangles --
+// each fence writes back the XCD's L2 -- against ~0.15 ms for all levels this way.)
+__global__ __launch_bounds__(256) void k_leaf_slots(const float4* __restrict__ tri_box, const uint32_t* __restrict__ order,
+                                                    int n, float pad, BoxSlot* __restrict__ slots)
 {
 	int j = blockIdx.x * 256 + threadIdx.x;
 	if (j >= n) return;
 	uint32_t prim = order[j];
 	float4 a = tri_box[2 * (size_t)prim], b = tri_box[2 * (size_t)prim + 1];
-	float mn[3] = {a.x - pad, a.y - pad, a.z - pad}, mx[3] = {b.x + pad, b.y + pad, b.z + pad};
 	BoxSlot* me = slots + (n - 1) + j;
-	for (int k = 0; k < 3; ++k) { me->mn[k] = mn[k]; me->mx[k] = mx[k]; }
-	int p = leaf_parent[j];
-	int self = ~j;
-	while (p >= 0) {
-		__threadfence();  // release my subtree box (agent scope: write back this XCD's L2)
-		unsigned int prev = atomicAdd(&arrive[p], 1u);
-		if (prev == 0u) return;  // the sibling subtree is not finished; its thread will continue
-		__threadfence();  // acquire: drop stale lines before reading the sibling's box
-		int sib = (left[p] == self) ? right[p] : left[p];
-		const BoxSlot* sb = (sib >= 0) ? (slots + sib) : (slots + (n - 1) + (~sib));
-		for (int k = 0; k < 3; ++k) {
-			float smn = __builtin_nontemporal_load(&sb->mn[k]);
-			float smx = __builtin_nontemporal_load(&sb->mx[k]);
-			mn[k] = fminf(mn[k], smn);
-			mx[k] = fmaxf(mx[k], smx);
-		}
-		BoxSlot* ps = slots + p;
-		for (int k = 0; k < 3; ++k) { ps->mn[k] = mn[k]; ps->mx[k] = mx[k]; }
-		self = p;
-		p = node_parent[p];
+	me->mn[0] = a.x - pad; me->mn[1] = a.y - pad; me->mn[2] = a.z - pad;
+	me->mx[0] = b.x + pad; me->mx[1] = b.y + pad; me->mx[2] = b.z + pad;
+}
+
+// depth of every internal node (root = 0) and the per-depth histogram
+constexpr int MAX_LEVELS = 128;
+__global__ __launch_bounds__(256) void k_node_depth(const int* __restrict__ node_parent, int n_internal, int* __restrict__ depth,
+                                                    int* __restrict__ hist)
+{
+	__shared__ int h[MAX_LEVELS];
+	if (threadIdx.x < MAX_LEVELS) h[threadIdx.x] = 0;
+	__syncthreads();
+	int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n_internal) {
+		int d = 0;
+		for (int p = node_parent[i]; p >= 0; p = node_parent[p]) ++d;
+		depth[i] = d;
+		atomicAdd(&h[min(d, MAX_LEVELS - 1)], 1);
+	}
+	__syncthreads();
+	if (threadIdx.x < MAX_LEVELS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_level_scatter(const int* __restrict__ depth, int n_internal, int* __restrict__ cursor,
+                                                       int* __restrict__ level_nodes)
+{
+	int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_internal) return;
+	// one returning atomic per (wave, depth value): lanes of equal depth take consecutive places
+	const int d = depth[i];
+	uint64_t todo = __ballot(1);
+	while (todo) {
+		const int lead = __ffsll((unsigned long long)todo) - 1;
+		const int dl = __shfl(d, lead);
+		const uint64_t same = __ballot(d == dl) & todo;
+		int base = 0;
+		if (lane_id() == lead) base = atomicAdd(&cursor[dl], (int)__popcll(same));
+		base = __shfl(base, lead);
+		if (d == dl) level_nodes[base + (int)__popcll(same & lanemask_lt())] = i;
+		todo &= ~same;
 	}
 }
 
@@ -371,16 +393,24 @@ __device__ __forceinline__ uint32_t quant_hi(float v, float org, float scale)
 	return (uint32_t)q;
 }
 
-__global__ __launch_bounds__(256) void k_emit_nodes(const BoxSlot* __restrict__ slots, int n,
+// list == nullptr: every internal node, boxes already in `slots` (the builders that make boxes as they go).
+// list != nullptr: the `count` nodes of one tree level; each also writes its own box = the union of its children's
+// (the level-by-level refit), so that the next launch, one level up, finds it.
+__global__ __launch_bounds__(256) void k_emit_nodes(BoxSlot* __restrict__ slots, int n, const int* __restrict__ list, int count,
                                                     const int* __restrict__ left, const int* __restrict__ right,
                                                     const int* __restrict__ node_parent, BvhNode* __restrict__ nodes,
                                                     QFrame qf, QNode* __restrict__ qnodes)
 {
-	int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= n - 1) return;
+	int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= count) return;
+	const int i = list ? list[k] : k;
 	int lc = left[i], rc = right[i];
 	const BoxSlot* l = (lc >= 0) ? (slots + lc) : (slots + (n - 1) + (~lc));
 	const BoxSlot* r = (rc >= 0) ? (slots + rc) : (slots + (n - 1) + (~rc));
+	if (list) {
+		BoxSlot* me = slots + i;
+		for (int a = 0; a < 3; ++a) { me->mn[a] = fminf(l->mn[a], r->mn[a]); me->mx[a] = fmaxf(l->mx[a], r->mx[a]); }
+	}
 	BvhNode nd;
 	nd.q0 = make_float4(l->mn[0], l->mn[1], l->mn[2], l->mx[0]);
 	nd.q1 = make_float4(l->mx[1], l->mx[2], r->mn[0], r->mn[1]);
@@ -456,6 +486,64 @@ static int tree_cost(rt_hip_ctx* ctx, const BoxSlot* slots, int n, float* cost)
 	const float root = dx * dy + (dy * dz + dz * dx);
 	*cost = root > 0.0f ? h[0] / root : 0.0f;
 	return RT_HIP_OK;
+}
+
+// The internal nodes grouped by depth (ctx->d_level_nodes, ctx->level_offsets): computed once per topology, at the
+// first refit (or at the build, for the LBVH builder, which makes its boxes this way too).
+static int compute_levels(rt_hip_ctx* ctx, int n, const int* node_parent)
+{
+	hipStream_t st = ctx->stream;
+	const int ni = n - 1;
+	RT_CHECK(ctx->d_level_nodes.reserve(((size_t)2 * ni + 2 * MAX_LEVELS) * sizeof(int)));
+	int* level_nodes = ctx->d_level_nodes.as<int>();
+	int* depth = level_nodes + ni;
+	int* hist = depth + ni;
+	int* cursor = hist + MAX_LEVELS;
+	RT_HIP_CHECK(hipMemsetAsync(hist, 0, MAX_LEVELS * sizeof(int), st));
+	hipLaunchKernelGGL(k_node_depth, dim3((ni + 255) / 256), dim3(256), 0, st, node_parent, ni, depth, hist);
+	RT_HIP_CHECK(hipGetLastError());
+	int* h = (int*)ctx->h_small + 256;  // pinned
+	RT_HIP_CHECK(hipMemcpyAsync(h, hist, MAX_LEVELS * sizeof(int), hipMemcpyDeviceToHost, st));
+	RT_HIP_CHECK(hipStreamSynchronize(st));
+	if (h[MAX_LEVELS - 1] != 0) { rt_set_error("BVH deeper than %d levels", MAX_LEVELS - 1); return RT_HIP_ERR_LIMIT; }
+	ctx->level_offsets.assign(1, 0);
+	for (int d = 0; d < MAX_LEVELS && ctx->level_offsets.back() < ni; ++d) ctx->level_offsets.push_back(ctx->level_offsets.back() + h[d]);
+	if (ctx->level_offsets.back() != ni) { rt_set_error("BVH levels cover %d of %d nodes", ctx->level_offsets.back(), ni); return RT_HIP_ERR_STATE; }
+	for (size_t d = 0; d + 1 < ctx->level_offsets.size(); ++d) h[MAX_LEVELS + d] = ctx->level_offsets[d];
+	RT_HIP_CHECK(hipMemcpyAsync(cursor, h + MAX_LEVELS, (ctx->level_offsets.size() - 1) * sizeof(int), hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_level_scatter, dim3((ni + 255) / 256), dim3(256), 0, st, depth, ni, cursor, level_nodes);
+	RT_HIP_CHECK(hipGetLastError());
+	RT_HIP_CHECK(hipStreamSynchronize(st));  // h_small is reused
+	return RT_HIP_OK;
+}
+
+// Leaf boxes from the triangle boxes, then every level from the deepest to the root: box, float node and
+// quantised node of each internal node in one pass (ctx->qframe must be final).
+static int refit_by_levels(rt_hip_ctx* ctx, int n, float pad, const uint32_t* order, const int* left, const int* right,
+                           const int* node_parent, BoxSlot* slots)
+{
+	hipStream_t st = ctx->stream;
+	hipLaunchKernelGGL(k_leaf_slots, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad, slots);
+	const int* level_nodes = ctx->d_level_nodes.as<int>();
+	for (int d = (int)ctx->level_offsets.size() - 2; d >= 0; --d) {
+		const int lo = ctx->level_offsets[d], cnt = ctx->level_offsets[d + 1] - lo;
+		if (cnt <= 0) continue;
+		hipLaunchKernelGGL(k_emit_nodes, dim3((cnt + 255) / 256), dim3(256), 0, st, slots, n, level_nodes + lo, cnt, left, right,
+		                   node_parent, ctx->d_nodes.as<BvhNode>(), ctx->qframe, ctx->d_qnodes.as<QNode>());
+	}
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+static void set_qframe(rt_hip_ctx* ctx, float pad)
+{
+	// quantisation grid: the padded scene box, 65535 steps per axis (a flat axis gets a unit step)
+	for (int k = 0; k < 3; ++k) {
+		ctx->qframe.org[k] = ctx->bounds[k] - 2.0f * pad;
+		float e = (ctx->bounds[3 + k] + 2.0f * pad) - ctx->qframe.org[k];
+		ctx->qframe.scale[k] = e > 0.0f ? e / 65535.0f : 1.0f;
+		ctx->qframe.reach[k] = std::fabs(ctx->qframe.org[k]) + 65535.0f * ctx->qframe.scale[k];
+	}
 }
 
 // PLOC rounds on the sorted leaves: fills left/right/node_parent/leaf_parent and every node's box slot.
@@ -679,7 +767,7 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 		                               ctx->d_order_tmp.as<uint32_t>(), n, 63));
 	}
 
-	// topology arrays: left, right, node_parent (n-1 each), leaf_parent (n), arrive (n-1), depth (1)
+	// topology arrays: left, right, node_parent (n-1 each), leaf_parent (n); the measured depth behind d_flags' first n words
 	size_t ints = (size_t)4 * n + 8;
 	RT_CHECK(ctx->d_parent_leaf.reserve(ints * 4));
 	int* left = ctx->d_parent_leaf.as<int>();
@@ -689,7 +777,7 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 	RT_CHECK(ctx->d_flags.reserve((size_t)(n + 16) * 4));
 	unsigned int* arrive = ctx->d_flags.as<unsigned int>();
 	int* max_depth = (int*)(arrive + n);
-	RT_HIP_CHECK(hipMemsetAsync(arrive, 0, (size_t)(n + 16) * 4, st));
+	RT_HIP_CHECK(hipMemsetAsync(max_depth, 0, 64, st));
 	RT_CHECK(ctx->d_misc.reserve((size_t)(2 * n) * sizeof(BoxSlot)));
 	BoxSlot* slots = ctx->d_misc.as<BoxSlot>();
 
@@ -702,20 +790,20 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 		RT_CHECK(build_ploc(ctx, n, pad, order, left, right, node_parent, leaf_parent, slots));
 	} else {
 		hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, st, keys, n, left, right, node_parent, leaf_parent);
-		hipLaunchKernelGGL(k_refit, dim3(g), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad, left, right,
-		                   node_parent, leaf_parent, slots, arrive);
+		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_CHECK(ctx->d_nodes.reserve((size_t)(n - 1) * sizeof(BvhNode)));
 	RT_CHECK(ctx->d_qnodes.reserve((size_t)(n - 1) * sizeof(QNode)));
-	// quantisation grid: the padded scene box, 65535 steps per axis (a flat axis gets a unit step)
-	for (int k = 0; k < 3; ++k) {
-		ctx->qframe.org[k] = ctx->bounds[k] - 2.0f * pad;
-		float e = (ctx->bounds[3 + k] + 2.0f * pad) - ctx->qframe.org[k];
-		ctx->qframe.scale[k] = e > 0.0f ? e / 65535.0f : 1.0f;
-		ctx->qframe.reach[k] = std::fabs(ctx->qframe.org[k]) + 65535.0f * ctx->qframe.scale[k];
+	set_qframe(ctx, pad);
+	ctx->level_offsets.clear();  // new topology: the refit's level lists are made when first needed
+	if (!sah && !ploc) {
+		// the Karras hierarchy has no boxes yet: make them level by level, nodes in the same pass
+		RT_CHECK(compute_levels(ctx, n, node_parent));
+		RT_CHECK(refit_by_levels(ctx, n, pad, order, left, right, node_parent, slots));
+	} else {
+		hipLaunchKernelGGL(k_emit_nodes, dim3(g), dim3(256), 0, st, slots, n, (const int*)nullptr, n - 1, left, right, node_parent,
+		                   ctx->d_nodes.as<BvhNode>(), ctx->qframe, ctx->d_qnodes.as<QNode>());
 	}
-	hipLaunchKernelGGL(k_emit_nodes, dim3(g), dim3(256), 0, st, slots, n, left, right, node_parent,
-	                   ctx->d_nodes.as<BvhNode>(), ctx->qframe, ctx->d_qnodes.as<QNode>());
 	// leaf-ordered intersection records (tri_isect currently holds original order)
 	RT_CHECK(ctx->d_in_a.reserve((size_t)n * sizeof(TriIsect)));
 	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_in_a.p, ctx->d_tri_isect.p, (size_t)n * sizeof(TriIsect), hipMemcpyDeviceToDevice, st));
@@ -770,25 +858,15 @@ int rt_refit_lbvh(rt_hip_ctx* ctx, const TriIsect* d_isect_src, float* cost)
 	int* left = ctx->d_parent_leaf.as<int>();
 	int* right = left + n;
 	int* node_parent = right + n;
-	int* leaf_parent = node_parent + n;
-	unsigned int* arrive = ctx->d_flags.as<unsigned int>();
 	BoxSlot* slots = ctx->d_misc.as<BoxSlot>();
 	const uint32_t* order = ctx->d_leaf_order.as<uint32_t>();
 	float emax = 0.0f;
 	for (int k = 0; k < 3; ++k) emax = std::max(emax, ctx->bounds[3 + k] - ctx->bounds[k]);
 	if (!(emax > 0.0f)) emax = 1.0f;
 	const float pad = 1e-5f * emax;
-	RT_HIP_CHECK(hipMemsetAsync(arrive, 0, (size_t)n * 4, st));
-	hipLaunchKernelGGL(k_refit, dim3(g), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad, left, right, node_parent,
-	                   leaf_parent, slots, arrive);
-	for (int k = 0; k < 3; ++k) {
-		ctx->qframe.org[k] = ctx->bounds[k] - 2.0f * pad;
-		float e = (ctx->bounds[3 + k] + 2.0f * pad) - ctx->qframe.org[k];
-		ctx->qframe.scale[k] = e > 0.0f ? e / 65535.0f : 1.0f;
-		ctx->qframe.reach[k] = std::fabs(ctx->qframe.org[k]) + 65535.0f * ctx->qframe.scale[k];
-	}
-	hipLaunchKernelGGL(k_emit_nodes, dim3(g), dim3(256), 0, st, slots, n, left, right, node_parent, ctx->d_nodes.as<BvhNode>(),
-	                   ctx->qframe, ctx->d_qnodes.as<QNode>());
+	if (ctx->level_offsets.empty()) RT_CHECK(compute_levels(ctx, n, node_parent));
+	set_qframe(ctx, pad);
+	RT_CHECK(refit_by_levels(ctx, n, pad, order, left, right, node_parent, slots));
 	hipLaunchKernelGGL(k_permute_tris, dim3(g), dim3(256), 0, st, d_isect_src, order, n, ctx->d_tri_isect.as<TriIsect>());
 	RT_HIP_CHECK(hipGetLastError());
 	RT_CHECK(tree_cost(ctx, slots, n, cost));

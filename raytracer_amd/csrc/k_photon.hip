@@ -694,6 +694,20 @@ __global__ __launch_bounds__(64) void k_photon_lookup(GridDesc gd, const uint32_
 	}
 }
 
+// sorted (position | index, payload) records back to the 9-float layout in photon-index order
+__global__ __launch_bounds__(256) void k_photon_unpermute(const float4* __restrict__ pos, const float4* __restrict__ payload,
+                                                          int64_t n, PhotonRec* __restrict__ out)
+{
+	int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (s >= n) return;
+	const float4 p = pos[s], a = payload[2 * s], c = payload[2 * s + 1];
+	PhotonRec r;
+	r.p[0] = p.x; r.p[1] = p.y; r.p[2] = p.z;
+	r.e[0] = a.x; r.e[1] = a.y; r.e[2] = a.z;
+	r.d[0] = a.w; r.d[1] = c.x; r.d[2] = c.y;
+	out[__float_as_uint(p.w)] = r;
+}
+
 // census: the photons the mandatory first pass of all points reads (the cells of each point's cube)
 __global__ __launch_bounds__(256) void k_photon_census(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                        const float* __restrict__ qpos, int npts, float radius,
@@ -866,6 +880,15 @@ int rt_photon_lookup(rt_hip_ctx* ctx, const float* d_pos, int npts, float radius
 	gd.cell = ctx->photon_cell; gd.inv_cell = 1.0f / ctx->photon_cell;
 	hipLaunchKernelGGL(k_photon_lookup, dim3(std::min(npts, 64 * 1024)), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
 	                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), d_pos, npts, radius, d_rgb);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
+int rt_photon_unpermute(rt_hip_ctx* ctx, float* d_out)
+{
+	if (ctx->num_photons == 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_photon_unpermute, dim3(nblocks(ctx->num_photons, 256)), dim3(256), 0, ctx->stream, ctx->d_photons.as<float4>(),
+	                   ctx->d_photon_sorted.as<float4>(), ctx->num_photons, (PhotonRec*)d_out);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }

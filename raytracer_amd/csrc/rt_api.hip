@@ -360,7 +360,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
 	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list, &ctx->d_all_tiles,
-	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_fcount, &ctx->d_leaf_order};
+	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_fcount, &ctx->d_leaf_order, &ctx->d_photon_emit, &ctx->d_level_nodes};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);
@@ -545,6 +545,17 @@ int rt_hip_set_model_mat(rt_hip_ctx* ctx, int mesh_id, const float* model_mat16)
 	if (!ctx->cfg.use_model_mat || ctx->cfg.geometry != RT_HIP_TRIANGLES) return RT_HIP_OK;
 	ctx->dirty_xf = true;
 	ctx->scene_dirty = true;
+	return RT_HIP_OK;
+}
+
+int rt_hip_set_model_mats(rt_hip_ctx* ctx, int first_mesh, int n, const float* model_mats16)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (first_mesh < 0 || n < 0 || (int64_t)first_mesh + n > (int64_t)ctx->meshes.size() || (n > 0 && !model_mats16)) {
+		rt_set_error("bad mesh range [%d, %d) of %zu meshes", first_mesh, first_mesh + n, ctx->meshes.size());
+		return RT_HIP_ERR_ARG;
+	}
+	for (int i = 0; i < n; ++i) RT_CHECK(rt_hip_set_model_mat(ctx, first_mesh + i, model_mats16 + 16 * (size_t)i));
 	return RT_HIP_OK;
 }
 
@@ -877,6 +888,35 @@ int rt_hip_photon_emit_device(rt_hip_ctx* ctx, int photons_per_light, int64_t fi
 		return RT_HIP_ERR_ARG;
 	}
 	return rt_photon_emit(ctx, photons_per_light, first, count, d_photons_out, capacity, out_stored);
+}
+
+int rt_hip_photon_generate(rt_hip_ctx* ctx, int photons_per_light, int64_t* out_stored)
+{
+	RT_CHECK(check_ready(ctx));
+	if (photons_per_light <= 0 || !out_stored) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	*out_stored = 0;
+	const int64_t total = (int64_t)photons_per_light * (int64_t)ctx->lights.size();
+	if (total == 0) return rt_photon_build_grid(ctx, nullptr, 0);
+	RT_CHECK(ctx->d_photon_emit.reserve((size_t)total * 36));
+	int64_t stored = 0;
+	RT_CHECK(rt_photon_emit(ctx, photons_per_light, 0, total, ctx->d_photon_emit.as<float>(), total, &stored));
+	RT_CHECK(rt_photon_build_grid(ctx, ctx->d_photon_emit.as<float>(), stored));
+	*out_stored = stored;
+	return RT_HIP_OK;
+}
+
+int rt_hip_photon_get(rt_hip_ctx* ctx, float* photons_out, int64_t capacity, int64_t* out_n)
+{
+	RT_CHECK(check_ctx(ctx));
+	if (!out_n || capacity < 0 || (capacity > 0 && !photons_out)) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	*out_n = ctx->num_photons;
+	if (ctx->num_photons == 0 || capacity == 0) return RT_HIP_OK;  // capacity 0: only the count is asked for
+	if (capacity < ctx->num_photons) { rt_set_error("capacity %lld < %lld photons in the map", (long long)capacity, (long long)ctx->num_photons); return RT_HIP_ERR_ARG; }
+	RT_CHECK(ctx->d_photon_tmp.reserve((size_t)ctx->num_photons * 36));
+	RT_CHECK(rt_photon_unpermute(ctx, ctx->d_photon_tmp.as<float>()));
+	RT_HIP_CHECK(hipMemcpyAsync(photons_out, ctx->d_photon_tmp.p, (size_t)ctx->num_photons * 36, hipMemcpyDeviceToHost, ctx->stream));
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	return RT_HIP_OK;
 }
 
 int rt_hip_photon_set_device(rt_hip_ctx* ctx, const float* d_photons, int64_t n)

@@ -138,6 +138,8 @@ struct rt_hip_ctx {
 	float bvh_cost_now = 0.0f;    // the same for the boxes in use (differs from bvh_cost_built after a refit)
 	float bvh_cost_built = 0.0f;  // sum of node half-areas / root half-area at the last build (refit quality check)
 	DevBuf d_leaf_order;          // leaf slot -> global triangle id of the BVH in use (kept for refits; d_order is scratch)
+	DevBuf d_level_nodes;         // internal node ids grouped by depth (the refit's launch lists), then the per-node depth
+	std::vector<int> level_offsets;  // level d = d_level_nodes[level_offsets[d], level_offsets[d + 1]); empty: not computed yet
 
 	// geometry in HBM
 	DevBuf d_verts, d_normals, d_texcoords, d_faces, d_mesh_of_tri, d_mesh_xf;  // inputs of the soup kernel
@@ -158,7 +160,7 @@ struct rt_hip_ctx {
 	void* h_small = nullptr;   // 4 KiB pinned scratch for counters
 
 	// photon map
-	DevBuf d_photons, d_photon_cell, d_photon_sorted, d_cell_start, d_photon_tmp, d_heavy;
+	DevBuf d_photons, d_photon_cell, d_photon_sorted, d_cell_start, d_photon_tmp, d_heavy, d_photon_emit;
 	int64_t num_photons = 0;
 	float photon_cell = 1.0f;
 	float photon_grid_min[3];
@@ -240,6 +242,7 @@ int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n);
 int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int npts, int count, float radius,
                      float* d_rgb);
 int rt_photon_lookup(rt_hip_ctx* ctx, const float* d_pos, int npts, float radius, float* d_rgb);
+int rt_photon_unpermute(rt_hip_ctx* ctx, float* d_out);  // the installed set in photon-index order, num_photons x 9 floats
 
 // ---- shared device-scan / multisplit helpers (k_sort.hip) -----------------------------------------
 // Stable counting-sort pass on an 8-bit digit: out_rank[i] = destination of element i.

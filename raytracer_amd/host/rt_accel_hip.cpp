@@ -148,6 +148,74 @@ bool AccelHip::occlude(Ray* ray)
 	return occ != 0;
 }
 
+// ---- PhotonMapHip ------------------------------------------------------------------------------
+PhotonMapHip::PhotonMapHip(unsigned long long seed_) : accel(0), seed(seed_), stored(0) {}
+
+void PhotonMapHip::generate(const Scene* scene, IAccel* meshes, int count)
+{
+	stored = 0;
+	accel = dynamic_cast<AccelHip*>(meshes);
+	if (!accel || !accel->ctx) {
+		fprintf(stderr, "PhotonMapHip::generate: the IAccel must be a usable AccelHip (the photons are traced on the GPU)\n");
+		accel = 0;
+		return;
+	}
+	rt_hip_ctx* ctx = accel->ctx;
+	accel->sync();                                     // meshes + materials
+	std::vector<rt_light> lights(scene->lights.size());
+	for (size_t i = 0; i < lights.size(); ++i) memcpy(&lights[i], scene->lights[i], sizeof(rt_light));  // identical layout
+	rt_hip_config cfg;
+	rt_hip_array_config(&cfg);                         // AccelHip's semantics; only the shading / photon fields are taken
+	cfg.seed = seed;                                   // max_dist 12, absorb 0.6: the reference's constants (rt_photon_map.cpp:92,45)
+	cfg.use_photon_map = 1;
+	long long n = 0;
+	if (rt_hip_set_config(ctx, &cfg) != RT_HIP_OK || rt_hip_set_lights(ctx, lights.empty() ? 0 : &lights[0], (int)lights.size()) != RT_HIP_OK ||
+	    rt_hip_update(ctx) != RT_HIP_OK || rt_hip_photon_generate(ctx, count, (int64_t*)&n) != RT_HIP_OK) {
+		fprintf(stderr, "PhotonMapHip::generate: %s\n", rt_hip_last_error());
+		return;
+	}
+	stored = n;
+}
+
+void PhotonMapHip::radianceEstimateBatch(const RtVec3* positions, const RtVec3* normals, int n, unsigned int count, float radius, RtVec3* out)
+{
+	if (n <= 0) return;
+	if (!accel || rt_hip_radiance_estimate(accel->ctx, (const float*)positions, (const float*)normals, n, (int)count, radius, (float*)out) != RT_HIP_OK) {
+		if (accel) fprintf(stderr, "PhotonMapHip::radiance_estimate: %s\n", rt_hip_last_error());
+		memset(out, 0, sizeof(RtVec3) * (size_t)n);
+	}
+}
+
+void PhotonMapHip::lookupBatch(const RtVec3* positions, int n, float radius, RtVec3* out)
+{
+	if (n <= 0) return;
+	if (!accel || rt_hip_photon_lookup(accel->ctx, (const float*)positions, n, radius, (float*)out) != RT_HIP_OK) {
+		if (accel) fprintf(stderr, "PhotonMapHip::lookup: %s\n", rt_hip_last_error());
+		memset(out, 0, sizeof(RtVec3) * (size_t)n);
+	}
+}
+
+RtVec3 PhotonMapHip::radiance_estimate(RtVec3 position, RtVec3, RtVec3 normal, unsigned int count, float radius)
+{
+	RtVec3 out;
+	radianceEstimateBatch(&position, &normal, 1, count, radius, &out);
+	return out;
+}
+
+RtVec3 PhotonMapHip::lookup(RtVec3 position, float radius)
+{
+	RtVec3 out;
+	lookupBatch(&position, 1, radius, &out);
+	return out;
+}
+
+long long PhotonMapHip::photons(float* out9, long long capacity)
+{
+	long long n = 0;
+	if (!accel || rt_hip_photon_get(accel->ctx, out9, capacity, (int64_t*)&n) != RT_HIP_OK) return 0;
+	return capacity == 0 ? 0 : n;
+}
+
 // ---- RayTracerHip ------------------------------------------------------------------------------
 RayTracerHip::RayTracerHip(int device) : ctx(0), dirty(true)
 {
@@ -193,13 +261,19 @@ void RayTracerHip::processRays(const Camera&, int count, RtVec3* positions, RtVe
 	*results = 0;
 	*result_offsets = 0;
 	if (!ctx) return;
-	// The reference re-reads every model_mat each frame (rt_raytracer.cpp:467); push them and rebuild.
+	// The reference re-reads every model_mat each frame (rt_raytracer.cpp:467) and rebuilds its soup; here the
+	// matrices are pushed and rt_hip_update does only what changed: nothing, or a refit of the kept BVH.
 	for (size_t i = 0; i < meshes.size(); ++i) rt_hip_set_model_mat(ctx, (int)i, meshes[i]->model_mat.data());
-	static Material zero_material;
-	std::vector<Material*> table(materials);
-	for (size_t i = 0; i < table.size(); ++i)
-		if (!table[i]) table[i] = &zero_material;
-	upload_materials(ctx, table);
+	if (dirty) {
+		// processRays' output depends on WHICH Material* a triangle carries, never on the material's contents
+		// (rt_raytracer.cpp:510-539), so the table only goes up when meshes were added
+		static Material zero_material;
+		std::vector<Material*> table(materials);
+		for (size_t i = 0; i < table.size(); ++i)
+			if (!table[i]) table[i] = &zero_material;
+		upload_materials(ctx, table);
+		dirty = false;
+	}
 	if (rt_hip_update(ctx) != RT_HIP_OK) { fprintf(stderr, "RayTracerHip: %s\n", rt_hip_last_error()); return; }
 	const rt_ray* res = 0;
 	const rt_result_offset* off = 0;

@@ -5,6 +5,7 @@
 // static_asserts in rt_accel_hip.cpp hold for both.
 #pragma once
 #include <utility>
+#include <vector>
 
 struct Vec3f { float v[3]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
 struct Vec2f { float v[2]; };
@@ -43,6 +44,16 @@ public:
 	Material* material;
 };
 class Camera;
+class Scene {                   // data/scene.h:6-21 (members only)
+public:
+	std::vector<Light*> lights;
+	std::vector<Mesh*> meshes;
+	std::vector<Material*> materials;
+	std::vector<Texture*> textures;
+	class Camera* camera;
+	class RayTracer* raytracer;
+	class Rasterizer* rasterizer;
+};
 class IAccel {                  // raytracer/rt_iaccel.h:4-11
 public:
 	virtual void addMesh(class Mesh* mesh) = 0;

@@ -75,3 +75,37 @@ def test_ray_tracer_hip_process_rays_signature(dropin, oracle_cls):
         for m in gb:
             for f in ("origin", "direction", "position", "normal", "texcoord"):
                 assert_bits_equal(ga[m][f], gb[m][f], "%s of material %d" % (f, m))
+
+
+def test_photon_map_hip_reference_shaped_sequence(dropin, oracle_cls):
+    """PhotonMapHip in PhotonMap's place (rt_photon_map.h:13-16): generate (rt_raytracer.cpp:165-167), then
+    radiance_estimate per shading point (:155-157) and lookup, called by code compiled against the reference's own
+    headers.  The photons equal the oracle's under the same counter RNG bit for bit; the estimates equal the oracle's
+    on those photons to 2e-5 (order of the float sum), NaN where no photon is in range."""
+    sc = scenes.cornell()
+    dropin.load_scene(sc)
+    dropin.lib.dropin_reset()
+    L = dropin.lib
+    L.dropin_photon_map_hip.restype = C.c_longlong
+    L.dropin_photon_map_hip.argtypes = [C.c_int, C.c_ulonglong, C.c_int, pyoracle.c_float_p, pyoracle.c_float_p, C.c_uint, C.c_float,
+                                        C.c_int, pyoracle.c_float_p, pyoracle.c_float_p, pyoracle.c_float_p, C.c_longlong]
+    orc = oracle_cls(sc)
+    nr, po = orc.software_gbuffer(48, 36)
+    pos, nrm, _ = orc.gbuffer_select(nr, po)
+    per_light, seed, k, radius = 4000, 42, 100, 1.0
+    cap = per_light * len(sc.lights)
+    est = np.zeros_like(pos); look = np.zeros_like(pos)
+    ph = np.zeros((cap, 9), np.float32)
+    n = L.dropin_photon_map_hip(per_light, seed, pos.shape[0], pos.ctypes.data_as(pyoracle.c_float_p),
+                                nrm.ctypes.data_as(pyoracle.c_float_p), k, radius, 40, est.ctypes.data_as(pyoracle.c_float_p),
+                                look.ctypes.data_as(pyoracle.c_float_p), ph.ctypes.data_as(pyoracle.c_float_p), cap)
+    assert n > per_light // 2, n
+    exp_ph = orc.photon_generate(per_light, geometry=0, rng=1, seed=seed)
+    assert_bits_equal(ph[:n], exp_ph, "photons of PhotonMapHip::generate")
+    orc.photon_set(exp_ph)
+    exp = orc.radiance_estimate(pos, nrm, k, radius)
+    np.testing.assert_array_equal(np.isnan(exp), np.isnan(est))
+    ok = ~np.isnan(exp)
+    assert ok.mean() > 0.5
+    np.testing.assert_allclose(est[ok], exp[ok], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(look, orc.photon_lookup(pos, radius), rtol=2e-5, atol=1e-9)

@@ -88,10 +88,11 @@ def test_update_does_the_least_that_is_needed(rt, oracle_cls):
     ref = g.process_rays(pos, nrm)
     kind = lambda: g.stats()["last_update"]
     # the reference's processRays re-reads every model matrix each call: the same matrices change nothing
-    for i, m in enumerate(sc.meshes):
-        g.set_model_mat(i, m.model_colmajor())
+    g.set_model_mats(0, np.stack([m.model_colmajor() for m in sc.meshes]))     # all meshes in one call
     g.update()
     assert kind() == rt.UPDATE_NONE
+    with pytest.raises(rt.RtHipError, match="mesh range"):
+        g.set_model_mats(len(sc.meshes) - 1, np.zeros((2, 16), np.float32))
     _same_results(g.process_rays(pos, nrm), ref, "unchanged matrices")
     # materials / lights: tables only
     g.load_scene_tables(sc)
