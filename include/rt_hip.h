@@ -414,6 +414,30 @@ int rt_hip_radiance_estimate(rt_hip_ctx* ctx, const float* pos, const float* nrm
 int rt_hip_photon_lookup_device(rt_hip_ctx* ctx, const float* d_pos, int npts, float radius, float* d_rgb_out);
 int rt_hip_photon_lookup(rt_hip_ctx* ctx, const float* pos, int npts, float radius, float* rgb_out);
 
+/* ---- multi-GPU: one process and one context per GPU, RCCL over xGMI ---------------------- */
+/* No counterpart in the reference (one thread, one GL context).  The frame is split by interleaved tile x tile
+ * screen tiles (tile k of a row-rotated round robin belongs to rank (tx + ty) % nranks), scene and BVH replicated
+ * on every GPU; the photon pass is sharded by photon index.  RCCL is used for exactly two exchange steps: the
+ * all-gather of the finished tiles and the all-gather of the photon shards.  librccl is bound at run time
+ * (dlopen), only when these entries are used.
+ * Bootstrap: rank 0 calls rt_hip_comm_unique_id and hands the RT_HIP_COMM_ID_BYTES bytes to the other ranks by the
+ * caller's own means (MPI, a file, a socket, torch.distributed ...); then EVERY rank calls rt_hip_comm_init
+ * (collective: it returns when all ranks have called it).  At most 16 ranks. */
+#define RT_HIP_COMM_ID_BYTES 128
+int rt_hip_comm_unique_id(void* id128);
+int rt_hip_comm_init(rt_hip_ctx* ctx, const void* id128, int rank, int nranks);
+int rt_hip_comm_destroy(rt_hip_ctx* ctx);   /* also done by rt_hip_destroy */
+/* One frame over all ranks (strong scaling; collective): this rank shades its tiles of the frame, the packed tiles
+ * are all-gathered, and every rank ends up with the whole RGBA8 image in d_rgba_out -- bit for bit the image
+ * rt_hip_render_frame_device renders on one GPU.  tile: a multiple of 8 (64 is what bench.py uses).
+ * rt_hip_last_frame_rays() = this rank's rays. */
+int rt_hip_render_frame_multi_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
+                                     int height, int tile, uint8_t* d_rgba_out);
+/* PhotonMap::generate over all ranks (collective): each rank emits its contiguous range of the global photon index
+ * sequence, the shards are all-gathered in rank (= index) order, and every rank installs the full set -- the
+ * photon array rt_hip_photon_generate makes on one GPU, bit for bit.  *out_stored = photons in the map. */
+int rt_hip_photon_generate_multi(rt_hip_ctx* ctx, int photons_per_light, int64_t* out_stored);
+
 /* ---- introspection ------------------------------------------------------------------------- */
 int rt_hip_get_stats(rt_hip_ctx* ctx, rt_hip_stats* out);
 int rt_hip_reset_stats(rt_hip_ctx* ctx);

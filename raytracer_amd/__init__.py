@@ -80,7 +80,8 @@ ABI_SYMBOLS = [
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device", "rt_hip_gbuffer_select_noalloc_device",
-    "rt_hip_set_model_mats", "rt_hip_photon_generate", "rt_hip_photon_get", "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
+    "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device",
+    "rt_hip_photon_generate_multi", "rt_hip_set_model_mats", "rt_hip_photon_generate", "rt_hip_photon_get", "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
 ]
 
 
@@ -164,6 +165,11 @@ def load_library() -> C.CDLL:
     L.rt_hip_unpack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
     L.rt_hip_shade_results.argtypes = [P, P, P, C.c_int, C.c_int, c_float_p, P]
     L.rt_hip_shade_results_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
+    L.rt_hip_comm_unique_id.argtypes = [P]
+    L.rt_hip_comm_init.argtypes = [P, P, C.c_int, C.c_int]
+    L.rt_hip_comm_destroy.argtypes = [P]
+    L.rt_hip_render_frame_multi_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_photon_generate_multi.argtypes = [P, C.c_int, C.POINTER(C.c_int64)]
     L.rt_hip_get_tuning.argtypes = [P, C.POINTER(Tuning)]
     L.rt_hip_set_tuning.argtypes = [P, C.POINTER(Tuning)]
     L.rt_hip_invalidate.argtypes = [P]
@@ -181,6 +187,18 @@ def load_library() -> C.CDLL:
 
 class RtHipError(RuntimeError):
     pass
+
+
+COMM_ID_BYTES = 128   # RT_HIP_COMM_ID_BYTES
+
+
+def comm_unique_id() -> bytes:
+    """rt_hip_comm_unique_id: call on rank 0, hand the bytes to every rank's RtHip.comm_init."""
+    L = load_library()
+    buf = (C.c_char * COMM_ID_BYTES)()
+    if L.rt_hip_comm_unique_id(buf) < 0:
+        raise RtHipError(L.rt_hip_last_error().decode())
+    return bytes(buf)
 
 
 def _f(a):
@@ -479,6 +497,27 @@ class RtHip:
 
     def last_frame_rays(self):
         return int(self.lib.rt_hip_last_frame_rays(self.h))
+
+    # ---- multi-GPU behind the C ABI (RCCL called by the library) ----------------------------------
+    def comm_init(self, rank, nranks, unique_id=None, broadcast=None):
+        """rt_hip_comm_init.  unique_id: the 128 bytes rank 0 got from comm_unique_id(); or pass `broadcast`, a callable
+        that takes rank 0's bytes (None on other ranks) and returns them on every rank (e.g. over torch.distributed)."""
+        if unique_id is None:
+            mine = comm_unique_id() if rank == 0 else None
+            unique_id = broadcast(mine) if broadcast else mine
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self._ck(self.lib.rt_hip_comm_init(self.h, buf, rank, nranks))
+
+    def comm_destroy(self):
+        self._ck(self.lib.rt_hip_comm_destroy(self.h))
+
+    def render_frame_multi_device(self, d_pos_rgb, d_nrm_rgba, w, h, tile, d_rgba):
+        self._ck(self.lib.rt_hip_render_frame_multi_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, tile, _dptr(d_rgba)))
+
+    def photon_generate_multi(self, per_light):
+        stored = C.c_int64(0)
+        self._ck(self.lib.rt_hip_photon_generate_multi(self.h, per_light, C.byref(stored)))
+        return stored.value
 
     # ---- photons --------------------------------------------------------------------------
     def photon_emit_device(self, per_light, first, count, d_out, capacity):

@@ -352,6 +352,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	if (!ctx) return RT_HIP_OK;
 	(void)hipSetDevice(ctx->cfg.device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	if (ctx->comm) (void)rt_hip_comm_destroy(ctx);
 	DevBuf* bufs[] = {&ctx->d_verts, &ctx->d_normals, &ctx->d_texcoords, &ctx->d_faces, &ctx->d_mesh_of_tri, &ctx->d_mesh_xf,
 	                  &ctx->d_tri_pos, &ctx->d_tri_attr, &ctx->d_tri_isect, &ctx->d_tri_box, &ctx->d_nodes, &ctx->d_qnodes, &ctx->d_spheres,
 	                  &ctx->d_materials, &ctx->d_lights, &ctx->d_morton, &ctx->d_morton_tmp, &ctx->d_order, &ctx->d_order_tmp,
@@ -360,7 +361,8 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
 	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list, &ctx->d_all_tiles,
-	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_fcount, &ctx->d_leaf_order, &ctx->d_photon_emit, &ctx->d_level_nodes};
+	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_fcount, &ctx->d_leaf_order, &ctx->d_photon_emit, &ctx->d_level_nodes,
+	                  &ctx->d_mg_send, &ctx->d_mg_recv, &ctx->d_mg_counts, &ctx->d_mg_photons};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);

@@ -166,6 +166,12 @@ struct rt_hip_ctx {
 	float photon_grid_min[3];
 	int photon_grid_dim[3];
 
+	// multi-GPU (k_comm.hip)
+	void* comm = nullptr;         // ncclComm_t
+	int comm_rank = 0, comm_nranks = 1;
+	int mg_key[4] = {0, 0, 0, 0}; // (w, h, tile, nranks) the send chunk was cleared for
+	DevBuf d_mg_send, d_mg_recv, d_mg_counts, d_mg_photons;
+
 	int last_count = 0;
 	int64_t last_frame_rays = 0;
 	rt_hip_stats stats;

@@ -1,0 +1,86 @@
+"""The multi-GPU entries of the C ABI (rt_hip_comm_*, rt_hip_render_frame_multi_device,
+rt_hip_photon_generate_multi: RCCL called by the library) on the one GPU a test box has: a ONE-rank communicator
+runs the same steps as N ranks -- librccl bound at run time, ncclCommInitRank, the tile all-gather and its unpack on
+the context's stream, the count all-gather and the grouped send/recv of the photon shards -- and must reproduce the
+single-GPU results bit for bit.  N > 1 is covered by index arithmetic on virtual ranks (test_gpu_parity.py,
+test_gpu_fullsize.py) and by the gloo tests; RCCL between real peers needs the 8-GPU node."""
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_rank_communicator_reproduces_single_gpu_results():
+    import torch
+    import raytracer_amd as rt
+    sc = scenes.atrium(2048)
+    g = rt.RtHip(sc, semantics="array", accel=rt.ACCEL_PLOC, bounces=2, do_shadows=1, shadow_t_max=1.0, seed=42)
+    w, h = 200, 150                   # not multiples of the tile: edge tiles carry padding
+    d_n = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+    d_p = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    g.render_gbuffer_device(sc.fov, w, h, d_n, d_p)
+    whole = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    g.render_frame_device(d_p, d_n, w, h, whole)
+    rays = g.last_frame_rays()
+    with pytest.raises(rt.RtHipError, match="rt_hip_comm_init"):
+        g.render_frame_multi_device(d_p, d_n, w, h, 64, whole)
+    g.comm_init(0, 1)
+    with pytest.raises(rt.RtHipError, match="already"):
+        g.comm_init(0, 1)
+    for tile in (64, 16):
+        out = torch.full((w * h * 4,), 7, dtype=torch.uint8, device="cuda")
+        g.render_frame_multi_device(d_p, d_n, w, h, tile, out)
+        assert torch.equal(out, whole), "tile %d" % tile
+        assert g.last_frame_rays() == rays
+    again = torch.zeros_like(whole)
+    g.render_frame_device(d_p, d_n, w, h, again)       # the single-GPU entry is undisturbed
+    assert torch.equal(again, whole)
+    # the photon pass
+    per_light = 3000
+    n1 = g.photon_generate(per_light)
+    a = g.photon_get()
+    n2 = g.photon_generate_multi(per_light)
+    b = g.photon_get()
+    assert n1 == n2 > per_light and a.tobytes() == b.tobytes()
+    g.comm_destroy()
+    g.comm_destroy()                  # idempotent
+    g.close()
+
+
+def test_torch_rccl_tile_all_gather_single_rank():
+    """raytracer_amd.frames.TileAllGather (what bench.py --scaling strong uses under torch.distributed) with the nccl
+    (= RCCL) backend and one rank: the collective runs on RCCL's stream, ordered against the context's stream by events
+    through torch.cuda.ExternalStream -- no host synchronisation -- and the assembled frame equals the whole frame."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd.frames import TileAllGather
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        sc = scenes.atrium(2048)
+        g = rt.RtHip(sc, semantics="array", accel=rt.ACCEL_PLOC, bounces=2, do_shadows=1, shadow_t_max=1.0)
+        w, h = 200, 150
+        d_n = torch.zeros(w * h * 4, dtype=torch.float32, device=dev)
+        d_p = torch.zeros(w * h * 3, dtype=torch.float32, device=dev)
+        g.render_gbuffer_device(sc.fov, w, h, d_n, d_p)
+        whole = torch.zeros(w * h * 4, dtype=torch.uint8, device=dev)
+        g.render_frame_device(d_p, d_n, w, h, whole)
+        x = TileAllGather(g, w, h, 64, 0, 1, dev)
+        for _ in range(3):                       # back to back: nothing but stream order between the steps
+            frame = torch.full((w * h * 4,), 9, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            x.render(d_p, d_n)
+            x.gather(frame)
+            g.sync()
+            assert torch.equal(frame, whole)
+        g.close()
+    finally:
+        dist.destroy_process_group()

@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -114,13 +115,14 @@ def test_photon_range_matches_full_sequence():
     assert np.array_equal(np.concatenate(parts, 0), whole)
 
 
-def test_two_rank_photon_gather_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_photon_gather_equals_single_rank(tmp_path, world):
     from oracle.pyoracle import Oracle
     sc = scenes.cornell()
     whole = Oracle(sc).photon_generate(PER_LIGHT, rng=1, seed=42)
     assert whole.shape[0] > 100
-    mp.spawn(_photon_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
+    mp.spawn(_photon_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "photons_%d.npy" % r))
         assert got.tobytes() == whole.tobytes()          # every rank holds the single-rank array, bit for bit
         assert np.load(os.path.join(str(tmp_path), "empty_%d.npy" % r)).shape == (0, 9)
@@ -190,9 +192,50 @@ def test_pack_unpack_roundtrip():
     np.testing.assert_array_equal(out, img)
 
 
-def test_two_rank_packed_exchange_assembles_frame_f_on_rank_f(tmp_path):
-    mp.spawn(_a2a_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    for f in range(2):
+def _allgather_worker(rank, world, port, out_dir):
+    """Strong scaling (bench.py --scaling strong, rt_hip_render_frame_multi_device): ONE frame split over the ranks, the
+    packed tiles all-gathered, the whole frame assembled on EVERY rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owner = tile_owner(W2, H2, TILE2, world)
+    mine = owner == rank
+    lists = [owned_tiles(W2, H2, TILE2, r, world) for r in range(world)]
+    chunk = max_owned_tiles(W2, H2, TILE2, world) * TILE2 * TILE2 * 4
+    orc, po, nrm, mid = _frame_inputs_fov(0.0)
+    rgba, _, rays = orc.render_texels(po, nrm, np.where(mine, mid, -1), bounces=2, do_shadows=1, shadow_t_max=1.0)
+    tiles = np.where(mine[:, None], rgba, 7).astype(np.uint8)
+    send = torch.zeros(chunk, dtype=torch.uint8)
+    packed = pack_tiles(tiles, W2, H2, TILE2, lists[rank]).reshape(-1)
+    send[:packed.shape[0]] = torch.from_numpy(packed)
+    recv = torch.zeros(world * chunk, dtype=torch.uint8)
+    dist.all_gather_into_tensor(recv, send)
+    frame = np.full((W2 * H2, 4), 9, np.uint8)
+    for r in range(world):
+        unpack_tiles(recv[r * chunk:(r + 1) * chunk].numpy(), W2, H2, TILE2, lists[r], frame)
+    total = torch.tensor([rays], dtype=torch.int64)
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    dist.barrier()
+    np.save(os.path.join(out_dir, "strong_%d.npy" % rank), frame)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "strong_rays.npy"), total.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strong_scaling_all_gather_assembles_the_frame_on_every_rank(tmp_path, world):
+    mp.spawn(_allgather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    orc, po, nrm, mid = _frame_inputs_fov(0.0)
+    full, _, rays = orc.render_texels(po, nrm, mid, bounces=2, do_shadows=1, shadow_t_max=1.0)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "strong_%d.npy" % r)), full)
+    assert int(np.load(os.path.join(str(tmp_path), "strong_rays.npy"))[0]) == rays      # the ranks' rays add up to the frame's
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_packed_exchange_assembles_frame_f_on_rank_f(tmp_path, world):
+    mp.spawn(_a2a_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for f in range(world):
         orc, po, nrm, mid = _frame_inputs_fov(-0.03 * f)
         full, _, _ = orc.render_texels(po, nrm, mid, bounces=2, do_shadows=1, shadow_t_max=1.0)
         got = np.load(os.path.join(str(tmp_path), "frame_%d.npy" % f))
