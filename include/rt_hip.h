@@ -148,7 +148,11 @@ typedef struct rt_hip_tuning {
 	int max_bvh_depth;        /* 95   deepest BVH the traversal stack takes (<= 95); a deeper tree is not used: brute force serves the scene */
 	float refit_max_growth;   /* 2.0  RT_HIP_REFIT_GROWTH: refit is kept while (sum of node areas / root area) stays below this multiple
 	                                 of its value at the last build; 0 = never refit, always rebuild */
-	int reserved[6];
+	int gather_fine;          /* 1    RT_HIP_GATHER_FINE: the wave-per-point gather walks the fine photon grid (cell = radius / 8) and reads
+	                                 only the boundary shell in its first pass; 0 = the coarse grid, every photon of the cube read */
+	int gather_xcd_chunk;     /* 1024 RT_HIP_GATHER_XCD_CHUNK: consecutive queued shading points per XCD in the wave-per-point gather (their
+	                                 neighbourhoods overlap, so the XCD's L2 serves most of their photon reads); 0 = hardware order */
+	int reserved[4];
 } rt_hip_tuning;
 
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent

@@ -173,21 +173,30 @@ __global__ __launch_bounds__(256) void k_photon_cell_keys(const PhotonRec* __res
 __global__ __launch_bounds__(256) void k_photon_permute(const PhotonRec* __restrict__ ph,
                                                         const uint32_t* __restrict__ order,
                                                         const uint64_t* __restrict__ keys, int64_t n, int ncells,
-                                                        float4* __restrict__ pos, float4* __restrict__ payload,
-                                                        uint32_t* __restrict__ cell_start)
+                                                        float4* __restrict__ pos, float4* __restrict__ payload)
 {
 	int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	(void)keys; (void)ncells;
 	if (s >= n) return;
 	const PhotonRec r = ph[order[s]];
 	pos[s] = make_float4(r.p[0], r.p[1], r.p[2], __uint_as_float(order[s]));
 	payload[2 * s] = make_float4(r.e[0], r.e[1], r.e[2], r.d[0]);
 	payload[2 * s + 1] = make_float4(r.d[1], r.d[2], 0.0f, 0.0f);
-	// cell_start[c] = first sorted slot of cell c; filled for every cell in (prev_cell, this_cell]
-	uint32_t c = (uint32_t)keys[s];
-	uint32_t prev = (s == 0) ? 0xFFFFFFFFu : (uint32_t)keys[s - 1];
-	if (s == 0) { for (uint32_t k = 0; k <= c; ++k) cell_start[k] = 0; }
-	else if (prev != c) { for (uint32_t k = prev + 1; k <= c; ++k) cell_start[k] = (uint32_t)s; }
-	if (s == n - 1) { for (uint32_t k = c + 1; k <= (uint32_t)ncells; ++k) cell_start[k] = (uint32_t)n; }
+}
+
+// cell_start[c] = first sorted slot whose cell id is >= c (lower bound on the sorted keys), for c in [0, ncells]:
+// one thread per cell, so a sparse grid costs log2(n) reads per cell instead of one thread walking a long gap.
+__global__ __launch_bounds__(256) void k_photon_cell_start(const uint64_t* __restrict__ keys, int64_t n, int ncells,
+                                                           uint32_t* __restrict__ cell_start)
+{
+	int c = blockIdx.x * 256 + threadIdx.x;
+	if (c > ncells) return;
+	int64_t lo = 0, hi = n;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if (keys[mid] < (uint64_t)c) lo = mid + 1; else hi = mid;
+	}
+	cell_start[c] = (uint32_t)lo;
 }
 
 // ---- gather -------------------------------------------------------------------------------------
@@ -272,38 +281,93 @@ __device__ __forceinline__ uint32_t cube_population(const GridDesc& gd, const ui
 	return total;
 }
 
-// The same walk with the 64 lanes of a wave striding over every span (P and rho are wave-uniform):
-// f(slot, l2, active) runs in uniform control flow, `active` false in the padding of a span's last chunk.
+// The wave visits every sorted slot of 64 runs [r0, r1), one run held per lane (empty: r1 <= r0).  A point's
+// neighbourhood is many short runs (one per grid row) and a wave that reads them one after the other waits one memory
+// round trip per run -- that, not the bytes, bounded the gather (~140 us per point).  So: runs of 256 slots and more
+// are read one at a time with coalesced 1-KB loads, four in flight; all shorter runs are FLATTENED -- a prefix sum of
+// their lengths across the lanes, then element e of the concatenation belongs to the run found by a 6-step binary
+// search over the lanes' prefix sums (shuffles) -- and read 256 elements per round, whatever run they belong to.
+// visit(q, slot, active) runs in wave-uniform control flow.
+template <typename V>
+__device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, uint32_t r0, uint32_t r1, V visit)
+{
+	const int lane = lane_id();
+	uint32_t len = r1 > r0 ? r1 - r0 : 0u;
+	uint64_t longm = __ballot(len >= 256u);
+	while (longm) {
+		const int src = __ffsll((unsigned long long)longm) - 1;
+		longm &= longm - 1;
+		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)r0, src), b = (uint32_t)__builtin_amdgcn_readlane((int)r1, src);
+		uint32_t s = a;
+		for (; s + 256 <= b; s += 256) {
+			const float4 qa = pos[s + lane], qb = pos[s + 64 + lane], qc = pos[s + 128 + lane], qd = pos[s + 192 + lane];
+			visit(qa, s + lane, true); visit(qb, s + 64 + lane, true); visit(qc, s + 128 + lane, true); visit(qd, s + 192 + lane, true);
+		}
+		for (; s < b; s += 64) {
+			const bool act = s + lane < b;
+			float4 q = make_float4(0, 0, 0, 0);
+			if (act) q = pos[s + lane];
+			visit(q, s + lane, act);
+		}
+	}
+	if (len >= 256u) len = 0u;
+	uint32_t end = len;   // inclusive prefix sum over the lanes
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t y = __shfl_up(end, off);
+		if (lane >= off) end += y;
+	}
+	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
+	const uint32_t base = r0 - (end - len);   // slot of flattened element e inside this lane's run = base + e
+	for (uint32_t e0 = 0; e0 < total; e0 += 256) {
+		float4 q[4];
+		uint32_t slot[4];
+		bool act[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t e = e0 + 64u * k + lane;
+			act[k] = e < total;
+			int j = 0;   // the first lane whose prefix sum exceeds e
+#pragma unroll
+			for (int step = 32; step >= 1; step >>= 1)
+				if (__shfl(end, min(j + step - 1, 63)) <= e) j += step;
+			slot[k] = __shfl(base, min(j, 63)) + e;
+			q[k] = make_float4(0, 0, 0, 0);
+			if (act[k]) q[k] = pos[slot[k]];
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			if (e0 + 64u * k < total) visit(q[k], slot[k], act[k]);
+	}
+}
+
+// The walk of for_each_neighbour with a whole wave on one point (P and rho are wave-uniform): the grid rows of the cube
+// are dealt to the lanes, 64 at a time, each lane looks up its row's run, and the wave visits the 64 runs together.
+// f(slot, l2, active) runs in uniform control flow, `active` false in the padding.
 template <typename F>
 __device__ __forceinline__ void for_each_neighbour_wave(const GridDesc& gd, const uint32_t* __restrict__ cell_start,
                                                         const float4* __restrict__ pos, f3 P, float rho, F f)
 {
 	rho = rho * 1.0001f + 1e-30f;
-	int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
-	int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
-	const uint32_t lane = (uint32_t)lane_id();
-	for (int z = z0; z <= z1; ++z)
-		for (int y = y0; y <= y1; ++y) {
+	const int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
+	const int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
+	const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+	const int lane = lane_id();
+	for (int rbase = 0; rbase < nrows; rbase += 64) {
+		const int row = rbase + lane;
+		uint32_t s0 = 0, s1 = 0;
+		if (row < nrows) {
+			const int y = y0 + row % ny, z = z0 + row / ny;
 			int x0, x1;
-			if (!row_chord(gd, P, rho, y, z, x0, x1)) continue;
-			uint32_t row = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
-			const uint32_t s0 = cell_start[row + x0], s1 = cell_start[row + x1 + 1];
-			uint32_t s = s0;
-			for (; s + 128 <= s1; s += 128) {  // two coalesced 1-KB loads in flight
-				const float4 qa = pos[s + lane], qb = pos[s + 64 + lane];
-				f3 da = mk3(qa.x, qa.y, qa.z) - P, db = mk3(qb.x, qb.y, qb.z) - P;
-				f(s + lane, dot3(da, da), true);
-				f(s + 64 + lane, dot3(db, db), true);
-			}
-			for (; s < s1; s += 64) {
-				const uint32_t k = s + lane;
-				const bool act = k < s1;
-				float4 q = make_float4(0, 0, 0, 0);
-				if (act) q = pos[k];
-				f3 d = mk3(q.x, q.y, q.z) - P;
-				f(k, dot3(d, d), act);
+			if (row_chord(gd, P, rho, y, z, x0, x1)) {
+				const uint32_t rb = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
+				s0 = cell_start[rb + x0]; s1 = cell_start[rb + x1 + 1];
 			}
 		}
+		wave_visit_runs(pos, s0, s1, [&](const float4 q, uint32_t slot, bool act) {
+			const f3 d = mk3(q.x, q.y, q.z) - P;
+			f(slot, dot3(d, d), act);
+		});
+	}
 }
 
 __device__ __forceinline__ int wave_sum_i(int v)
@@ -320,6 +384,77 @@ __device__ __forceinline__ float wave_max_f(float v)
 {
 	for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
 	return v;
+}
+
+// Pass 1 of the wave-per-point gather on the fine grid: the number of photons within the radius and max_dist2 over ALL
+// of them (rt_photon_map.cpp:159-169) without reading all of them.  Per grid row (y, z) the cells along x split into
+// an INTERIOR run -- cells whose farthest corner lies inside the sphere: every photon in them is a candidate, so they
+// are counted from the cell table and not read -- and at most two SHELL runs at the ends of the chord, which are read.
+// The farthest candidate is almost always a shell photon; only if an interior run could hold a farther one (its far
+// corner is farther than the best shell candidate, e.g. an empty shell) is that run read too, in a second sweep.
+// Rows are dealt to the lanes for the table work, the wave then reads the 64 rows' shell runs together.
+template <bool SECOND>
+__device__ __forceinline__ void wave_shell_sweep(const GridDesc& gd, const uint32_t* __restrict__ cs, const float4* __restrict__ pos,
+                                                 f3 P, float radius, float r2, float mx_in, int& nc_l, float& mx_l, float& bound_l)
+{
+	const float rho = radius * 1.0001f + 1e-30f;
+	const int y0 = cell_coord(P.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(P.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
+	const int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
+	const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+	const int lane = lane_id();
+	// a photon sits in the cell floor((p - mn) / cell) computed in float: its coordinate may be off the cell's nominal
+	// box by a few ulps of the grid extent, far below a thousandth of a cell
+	const float slack = gd.cell * 1e-3f;
+	// 0.999: the interior runs' far corners then stay below 0.998 r^2, under the farthest shell candidate of any
+	// point with a few hundred photons around it, so the second sweep stays the exception
+	const float rin = radius * 0.999f;
+	for (int base = 0; base < nrows; base += 64) {
+		const int row = base + lane;
+		uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;  // the runs this lane's row contributes to the wave's reading
+		if (row < nrows) {
+			const int y = y0 + row % ny, z = z0 + row / ny;
+			int x0, x1;
+			if (row_chord(gd, P, rho, y, z, x0, x1)) {
+				const uint32_t rb = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
+				const uint32_t s0 = cs[rb + x0], s1 = cs[rb + x1 + 1];
+				if (!SECOND) { a0 = s0; a1 = s1; }
+				// the border cells of the grid also hold what cell_coord clamped into them: never interior
+				const bool border = y == 0 || y == gd.dim[1] - 1 || z == 0 || z == gd.dim[2] - 1;
+				if (s1 > s0 && !border) {
+					const float ylo = gd.mn[1] + (float)y * gd.cell, zlo = gd.mn[2] + (float)z * gd.cell;
+					const float dyf = fmaxf(fabsf(ylo - P.y), fabsf(ylo + gd.cell - P.y)) + slack;
+					const float dzf = fmaxf(fabsf(zlo - P.z), fabsf(zlo + gd.cell - P.z)) + slack;
+					const float h2 = rin * rin - (dyf * dyf + dzf * dzf);
+					if (h2 > 0.0f) {
+						const float half = rt_sqrtf(h2) * 0.9999f - slack;
+						int xi0 = (int)ceilf((P.x - half - gd.mn[0]) * gd.inv_cell + 1e-3f);
+						int xi1 = (int)floorf((P.x + half - gd.mn[0]) * gd.inv_cell - 1e-3f) - 1;
+						xi0 = max(xi0, max(x0, 1)); xi1 = min(xi1, min(x1, gd.dim[0] - 2));
+						if (xi0 <= xi1) {
+							const uint32_t i0 = cs[rb + xi0], i1 = cs[rb + xi1 + 1];
+							const float dxf = fmaxf(fabsf(gd.mn[0] + (float)xi0 * gd.cell - P.x),
+							                        fabsf(gd.mn[0] + (float)(xi1 + 1) * gd.cell - P.x)) + slack;
+							const float far2 = (dxf * dxf + (dyf * dyf + dzf * dzf)) * 1.0001f;  // >= every l2 in the run
+							if (!SECOND) {
+								nc_l += (int)(i1 - i0);
+								a1 = i0; b0 = i1; b1 = s1;
+								if (i1 > i0) bound_l = fmaxf(bound_l, far2);
+							} else if (i1 > i0 && far2 > mx_in) {
+								a0 = i0; a1 = i1;
+							}
+						}
+					}
+				}
+			}
+		}
+		auto visit = [&](const float4 q, uint32_t, bool act) {
+			const f3 d = mk3(q.x, q.y, q.z) - P;
+			const float l2 = dot3(d, d);
+			if (act && l2 < r2) { if (!SECOND) ++nc_l; mx_l = fmaxf(mx_l, l2); }
+		};
+		wave_visit_runs(pos, a0, a1, visit);
+		if (__ballot(b1 > b0)) wave_visit_runs(pos, b0, b1, visit);
+	}
 }
 
 // PhotonMap::radiance_estimate (rt_photon_map.cpp:149-208), one lane per shading point.
@@ -500,13 +635,14 @@ __global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uin
 // the wave's (LDS atomics), and the control flow of the selection is wave-uniform.  Same passes, same
 // bins, same tie rule (photons at the k-th distance are taken in walk order) as the per-lane kernel;
 // only the order of the floating-point sum differs (lane partial sums, then a butterfly).
+template <bool SHELL>
 __global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                            const float4* __restrict__ pos,
                                                            const float4* __restrict__ payload, int64_t nph,
                                                            const float* __restrict__ qpos, const float* __restrict__ qnrm,
                                                            const int* __restrict__ heavy_queue,
                                                            const int* __restrict__ heavy_count, int count, float radius,
-                                                           GatherConst gc, float* __restrict__ rgb)
+                                                           GatherConst gc, float* __restrict__ rgb, int xcd_chunk)
 {
 	__shared__ uint32_t s_hist[SEL_BINS];
 	__shared__ uint32_t s_list[SEL_LIST];
@@ -516,7 +652,10 @@ __global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const ui
 	const int lane = lane_id();
 	const int nheavy = *heavy_count;
 	const float r2 = radius * radius;
-	for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
+	// XCD-aware order (rt_trace_dev.h: xcd_block_index): XCD x takes `xcd_chunk` consecutive queue entries of every
+	// group of 8 * xcd_chunk.  Queue order is screen order, neighbouring points read nearly the same photons, and the
+	// heavy points are bound by the bandwidth those reads get: this way they come from the XCD's own L2.
+	for (int h = (int)xcd_block_index(xcd_chunk); h < nheavy; h += gridDim.x) {
 		const int i = __builtin_amdgcn_readfirstlane(heavy_queue[h]);
 		f3 P, N;
 		P.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 0])));
@@ -531,15 +670,23 @@ __global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const ui
 				if (k < upto) ok = ok && sel_bin(l2, lv[k].lo, lv[k].scale) == lv[k].bin;
 			return ok;
 		};
-		// pass 1: the number of photons within the radius and max_dist2 over all of them -- nothing else, this
-		// is the one pass that has to read every photon of the cube
+		// pass 1: the number of photons within the radius and max_dist2 over all of them; interiors are counted
+		// from the cell table, only the boundary shell is read (wave_shell_sweep)
 		int nc_l = 0;
-		float mx_l = 0.0f;
-		for_each_neighbour_wave(gd, cell_start, pos, P, radius, [&](uint32_t, float l2, bool act) {
-			if (act && l2 < r2) { ++nc_l; mx_l = fmaxf(mx_l, l2); }
-		});
+		float mx_l = 0.0f, bound_l = 0.0f;
+		if (SHELL) {
+			wave_shell_sweep<false>(gd, cell_start, pos, P, radius, r2, 0.0f, nc_l, mx_l, bound_l);
+		} else {
+			for_each_neighbour_wave(gd, cell_start, pos, P, radius, [&](uint32_t, float l2, bool act) {
+				if (act && l2 < r2) { ++nc_l; mx_l = fmaxf(mx_l, l2); }
+			});
+		}
 		const int nc = wave_sum_i(nc_l);
-		const float max_dist2 = wave_max_f(mx_l);
+		float max_dist2 = wave_max_f(mx_l);
+		if (SHELL && wave_max_f(bound_l) > max_dist2) {   // rare: an interior run could hold the farthest candidate
+			wave_shell_sweep<true>(gd, cell_start, pos, P, radius, r2, max_dist2, nc_l, mx_l, bound_l);
+			max_dist2 = wave_max_f(mx_l);
+		}
 		uint32_t tau = 0xFFFFFFFFu;
 		int take_equal = 0x7fffffff;
 		float rho_sel = radius;
@@ -767,6 +914,49 @@ int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count,
 	return RT_HIP_OK;
 }
 
+// One uniform grid over the photon bounds [mn, mx]: cell enlarged until the grid has at most max_cells cells; photons
+// counting-sorted by cell (rows along x are contiguous in the sorted arrays), cell_start by lower bound.
+static int build_one_grid(rt_hip_ctx* ctx, const PhotonRec* ph, int64_t n, const float* mn, const float* mx, float cell,
+                          double max_cells, DevBuf& d_pos, DevBuf& d_payload, DevBuf& d_cell_start, int* dim_out, float* cell_out)
+{
+	hipStream_t st = ctx->stream;
+	int dim[3];
+	for (;;) {
+		double cells = 1;
+		for (int k = 0; k < 3; ++k) {
+			dim[k] = std::max(1, (int)std::floor((mx[k] - mn[k]) / cell) + 1);
+			cells *= dim[k];
+		}
+		if (cells <= max_cells) break;
+		cell *= 1.5f;
+	}
+	const int ncells = dim[0] * dim[1] * dim[2];
+	GridDesc gd;
+	for (int k = 0; k < 3; ++k) { gd.mn[k] = mn[k]; gd.dim[k] = dim[k]; dim_out[k] = dim[k]; }
+	gd.cell = cell; gd.inv_cell = 1.0f / cell;
+	*cell_out = cell;
+	RT_CHECK(ctx->d_morton.reserve((size_t)n * 8));
+	RT_CHECK(ctx->d_morton_tmp.reserve((size_t)n * 8));
+	RT_CHECK(ctx->d_order.reserve((size_t)n * 4));
+	RT_CHECK(ctx->d_order_tmp.reserve((size_t)n * 4));
+	uint64_t* keys = ctx->d_morton.as<uint64_t>();
+	uint32_t* order = ctx->d_order.as<uint32_t>();
+	hipLaunchKernelGGL(k_photon_cell_keys, dim3(nblocks(n, 256)), dim3(256), 0, st, ph, n, gd, keys, order);
+	RT_HIP_CHECK(hipGetLastError());
+	int bits = 1;
+	while ((1ll << bits) < ncells) ++bits;
+	RT_CHECK(rt_radix_sort_pairs64(ctx, keys, ctx->d_morton_tmp.as<uint64_t>(), order, ctx->d_order_tmp.as<uint32_t>(), (int)n, bits));
+	RT_CHECK(d_pos.reserve((size_t)n * 16));
+	RT_CHECK(d_payload.reserve((size_t)n * 32));
+	RT_CHECK(d_cell_start.reserve((size_t)(ncells + 2) * 4));
+	hipLaunchKernelGGL(k_photon_permute, dim3(nblocks(n, 256)), dim3(256), 0, st, ph, order, keys, n, ncells, d_pos.as<float4>(),
+	                   d_payload.as<float4>());
+	hipLaunchKernelGGL(k_photon_cell_start, dim3(nblocks((int64_t)ncells + 1, 256)), dim3(256), 0, st, keys, n, ncells,
+	                   d_cell_start.as<uint32_t>());
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
 int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 {
 	hipStream_t st = ctx->stream;
@@ -782,43 +972,16 @@ int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 	RT_HIP_CHECK(hipMemcpyAsync(ob, ctx->d_bounds.p, sizeof(ob), hipMemcpyDeviceToHost, st));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	float mn[3], mx[3];
-	for (int k = 0; k < 3; ++k) { mn[k] = ord2f(ob[k]); mx[k] = ord2f(ob[3 + k]); }
-	// cell = photon_radius / 2 (the selection passes of the gather read only the cells under their
-	// current distance bound, so finer cells pay), enlarged until the grid has at most 2^22 cells
-	float cell = (ctx->cfg.photon_radius > 0.0f ? ctx->cfg.photon_radius : 1.0f) * 0.5f;
-	int dim[3];
-	for (;;) {
-		double cells = 1;
-		for (int k = 0; k < 3; ++k) {
-			dim[k] = std::max(1, (int)std::floor((mx[k] - mn[k]) / cell) + 1);
-			cells *= dim[k];
-		}
-		if (cells <= (double)(1 << 22)) break;
-		cell *= 1.5f;
-	}
-	int ncells = dim[0] * dim[1] * dim[2];
-	GridDesc gd;
-	for (int k = 0; k < 3; ++k) { gd.mn[k] = mn[k]; gd.dim[k] = dim[k]; ctx->photon_grid_min[k] = mn[k]; ctx->photon_grid_dim[k] = dim[k]; }
-	gd.cell = cell; gd.inv_cell = 1.0f / cell;
-	ctx->photon_cell = cell;
-
-	RT_CHECK(ctx->d_morton.reserve((size_t)n * 8));
-	RT_CHECK(ctx->d_morton_tmp.reserve((size_t)n * 8));
-	RT_CHECK(ctx->d_order.reserve((size_t)n * 4));
-	RT_CHECK(ctx->d_order_tmp.reserve((size_t)n * 4));
-	uint64_t* keys = ctx->d_morton.as<uint64_t>();
-	uint32_t* order = ctx->d_order.as<uint32_t>();
-	hipLaunchKernelGGL(k_photon_cell_keys, dim3(nblocks(n, 256)), dim3(256), 0, st, ph, n, gd, keys, order);
-	RT_HIP_CHECK(hipGetLastError());
-	int bits = 1;
-	while ((1ll << bits) < ncells) ++bits;
-	RT_CHECK(rt_radix_sort_pairs64(ctx, keys, ctx->d_morton_tmp.as<uint64_t>(), order, ctx->d_order_tmp.as<uint32_t>(), (int)n, bits));
-	RT_CHECK(ctx->d_photons.reserve((size_t)n * 16));
-	RT_CHECK(ctx->d_photon_sorted.reserve((size_t)n * 32));
-	RT_CHECK(ctx->d_cell_start.reserve((size_t)(ncells + 2) * 4));
-	hipLaunchKernelGGL(k_photon_permute, dim3(nblocks(n, 256)), dim3(256), 0, st, ph, order, keys, n, ncells,
-	                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->d_cell_start.as<uint32_t>());
-	RT_HIP_CHECK(hipGetLastError());
+	for (int k = 0; k < 3; ++k) { mn[k] = ord2f(ob[k]); mx[k] = ord2f(ob[3 + k]); ctx->photon_grid_min[k] = mn[k]; }
+	const float radius = ctx->cfg.photon_radius > 0.0f ? ctx->cfg.photon_radius : 1.0f;
+	// Two grids over the same photons.  Coarse, cell = radius / 2: what the lane-per-point gather walks (a point with
+	// few photons nearby pays per grid row, so rows must be few).  Fine, cell = radius / 8: what the wave-per-point
+	// gather of the photon-rich points walks -- cells entirely inside the sphere are counted from the cell table and
+	// only the boundary shell is read, and the selection passes read a neighbourhood as small as the k-th distance.
+	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius * 0.5f, (double)(1 << 22), ctx->d_photons, ctx->d_photon_sorted, ctx->d_cell_start,
+	                        ctx->photon_grid_dim, &ctx->photon_cell));
+	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius * 0.125f, (double)(1 << 25), ctx->d_photons_f, ctx->d_photon_sorted_f,
+	                        ctx->d_cell_start_f, ctx->photon_grid_dim_f, &ctx->photon_cell_f));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	ctx->num_photons = n;
 	return RT_HIP_OK;
@@ -858,10 +1021,22 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	RT_HIP_CHECK(hipGetLastError());
 	if (ctx->num_photons > 0) {
 		// one wave per queued point, grid-stride over a queue whose length only the device knows
-		const int waves = std::min(npts, 64 * 1024);
-		hipLaunchKernelGGL(k_photon_gather_wave, dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
-		                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-		                   heavy_queue, heavy_count, count, radius, gc, d_rgb);
+		// a multiple of 8 * chunk blocks, so that the XCD-aware renumbering is a bijection
+		const int chunk = ctx->tuning.gather_xcd_chunk;
+		const int unit = 8 * std::max(1, chunk);
+		const int waves = (std::min(npts, 64 * 1024) + unit - 1) / unit * unit;
+		if (ctx->tuning.gather_fine) {
+			GridDesc gf;
+			for (int k = 0; k < 3; ++k) { gf.mn[k] = ctx->photon_grid_min[k]; gf.dim[k] = ctx->photon_grid_dim_f[k]; }
+			gf.cell = ctx->photon_cell_f; gf.inv_cell = 1.0f / ctx->photon_cell_f;
+			hipLaunchKernelGGL(k_photon_gather_wave<true>, dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
+			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk);
+		} else {
+			hipLaunchKernelGGL(k_photon_gather_wave<false>, dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
+			                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->num_photons, d_pos, d_nrm,
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk);
+		}
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_CHECK(rt_end_trace_timing(ctx, 2));

@@ -91,6 +91,8 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->gather_heavy = 1024;
 	if (const char* e = getenv("RT_HIP_GATHER_HEAVY")) t->gather_heavy = (uint32_t)strtoul(e, nullptr, 10);
 	t->extra_lds_bytes = env_int("RT_HIP_EXTRA_LDS", 0);
+	t->gather_fine = env_int("RT_HIP_GATHER_FINE", 1);
+	t->gather_xcd_chunk = env_int("RT_HIP_GATHER_XCD_CHUNK", 1024);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
@@ -108,6 +110,8 @@ void rt_clamp_tuning(rt_hip_ctx* ctx)
 	if (t.auto_accel != RT_HIP_ACCEL_LBVH) t.auto_accel = RT_HIP_ACCEL_PLOC;
 	t.ploc_radius = std::min(64, std::max(1, t.ploc_radius));
 	t.frame_sync = t.frame_sync ? 1 : 0;
+	t.gather_fine = t.gather_fine ? 1 : 0;
+	t.gather_xcd_chunk = std::min(8192, std::max(0, t.gather_xcd_chunk));
 	t.extra_lds_bytes = std::min(64 * 1024, std::max(0, t.extra_lds_bytes));
 	t.max_bvh_depth = std::min(95, std::max(1, t.max_bvh_depth));
 	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;
@@ -362,7 +366,8 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
 	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list, &ctx->d_all_tiles,
 	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_fcount, &ctx->d_leaf_order, &ctx->d_photon_emit, &ctx->d_level_nodes,
-	                  &ctx->d_mg_send, &ctx->d_mg_recv, &ctx->d_mg_counts, &ctx->d_mg_photons};
+	                  &ctx->d_mg_send, &ctx->d_mg_recv, &ctx->d_mg_counts, &ctx->d_mg_photons,
+	                  &ctx->d_photons_f, &ctx->d_photon_sorted_f, &ctx->d_cell_start_f};
 	for (DevBuf* b : bufs) b->release();
 	for (auto& pr : ctx->trace_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);
