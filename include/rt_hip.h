@@ -152,7 +152,8 @@ typedef struct rt_hip_tuning {
 	                                 only the boundary shell in its first pass; 0 = the coarse grid, every photon of the cube read */
 	int gather_xcd_chunk;     /* 1024 RT_HIP_GATHER_XCD_CHUNK: consecutive queued shading points per XCD in the wave-per-point gather (their
 	                                 neighbourhoods overlap, so the XCD's L2 serves most of their photon reads); 0 = hardware order */
-	int reserved[4];
+	int gather_fine_cells;    /* 8    RT_HIP_GATHER_FINE_CELLS: fine photon grid cells per gather radius (2..32); read when a photon set is installed */
+	int reserved[3];
 } rt_hip_tuning;
 
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent

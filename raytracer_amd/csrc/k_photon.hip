@@ -281,6 +281,14 @@ __device__ __forceinline__ uint32_t cube_population(const GridDesc& gd, const ui
 	return total;
 }
 
+// row / ny by multiplication: umulhi(row, floor((2^32 - 1) / ny) + 1) == row / ny for every row < 2^16 and ny <= 4096
+// (checked exhaustively); a larger cube of rows takes the division.
+__device__ __forceinline__ uint32_t row_div_magic(int ny) { return 0xFFFFFFFFu / (uint32_t)ny + 1u; }
+__device__ __forceinline__ int row_div(int row, int ny, uint32_t magic, bool small)
+{
+	return small ? (int)__umulhi((uint32_t)row, magic) : row / ny;
+}
+
 // The wave visits every sorted slot of 64 runs [r0, r1), one run held per lane (empty: r1 <= r0).  A point's
 // neighbourhood is many short runs (one per grid row) and a wave that reads them one after the other waits one memory
 // round trip per run -- that, not the bytes, bounded the gather (~140 us per point).  So: runs of 256 slots and more
@@ -318,25 +326,36 @@ __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, 
 	}
 	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
 	const uint32_t base = r0 - (end - len);   // slot of flattened element e inside this lane's run = base + e
+	// Each lane takes FOUR consecutive elements of the concatenation per round: one binary search for the first, and the
+	// run of each next element is the same one or the next non-empty one (one shuffle to find out).
+	const uint64_t nonempty = __ballot(len > 0u);
 	for (uint32_t e0 = 0; e0 < total; e0 += 256) {
 		float4 q[4];
 		uint32_t slot[4];
 		bool act[4];
+		const uint32_t e = e0 + 4u * lane;
+		int j = 0;   // the first lane whose prefix sum exceeds e (never an empty run)
+#pragma unroll
+		for (int step = 32; step >= 1; step >>= 1)
+			if (__shfl(end, min(j + step - 1, 63)) <= e) j += step;
+		j = min(j, 63);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const uint32_t e = e0 + 64u * k + lane;
-			act[k] = e < total;
-			int j = 0;   // the first lane whose prefix sum exceeds e
-#pragma unroll
-			for (int step = 32; step >= 1; step >>= 1)
-				if (__shfl(end, min(j + step - 1, 63)) <= e) j += step;
-			slot[k] = __shfl(base, min(j, 63)) + e;
+			const uint32_t ek = e + k;
+			act[k] = ek < total;
+			if (k > 0) {
+				const uint32_t t = __shfl(end, j);
+				if (t <= ek) {
+					const uint64_t rest = j >= 63 ? 0ull : (nonempty >> (j + 1));
+					j = rest ? j + __ffsll((unsigned long long)rest) : 63;
+				}
+			}
+			slot[k] = __shfl(base, j) + ek;
 			q[k] = make_float4(0, 0, 0, 0);
 			if (act[k]) q[k] = pos[slot[k]];
 		}
 #pragma unroll
-		for (int k = 0; k < 4; ++k)
-			if (e0 + 64u * k < total) visit(q[k], slot[k], act[k]);
+		for (int k = 0; k < 4; ++k) visit(q[k], slot[k], act[k]);
 	}
 }
 
@@ -352,11 +371,14 @@ __device__ __forceinline__ void for_each_neighbour_wave(const GridDesc& gd, cons
 	const int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
 	const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
 	const int lane = lane_id();
+	const uint32_t ny_magic = row_div_magic(ny);
+	const bool rows_small = nrows < 65536 && ny <= 4096 && ny > 1;
 	for (int rbase = 0; rbase < nrows; rbase += 64) {
 		const int row = rbase + lane;
 		uint32_t s0 = 0, s1 = 0;
 		if (row < nrows) {
-			const int y = y0 + row % ny, z = z0 + row / ny;
+			const int zr = row_div(row, ny, ny_magic, rows_small);
+			const int y = y0 + (row - zr * ny), z = z0 + zr;
 			int x0, x1;
 			if (row_chord(gd, P, rho, y, z, x0, x1)) {
 				const uint32_t rb = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
@@ -402,6 +424,8 @@ __device__ __forceinline__ void wave_shell_sweep(const GridDesc& gd, const uint3
 	const int z0 = cell_coord(P.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(P.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
 	const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
 	const int lane = lane_id();
+	const uint32_t ny_magic = row_div_magic(ny);
+	const bool rows_small = nrows < 65536 && ny <= 4096 && ny > 1;
 	// a photon sits in the cell floor((p - mn) / cell) computed in float: its coordinate may be off the cell's nominal
 	// box by a few ulps of the grid extent, far below a thousandth of a cell
 	const float slack = gd.cell * 1e-3f;
@@ -412,7 +436,8 @@ __device__ __forceinline__ void wave_shell_sweep(const GridDesc& gd, const uint3
 		const int row = base + lane;
 		uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;  // the runs this lane's row contributes to the wave's reading
 		if (row < nrows) {
-			const int y = y0 + row % ny, z = z0 + row / ny;
+			const int zr = row_div(row, ny, ny_magic, rows_small);
+			const int y = y0 + (row - zr * ny), z = z0 + zr;
 			int x0, x1;
 			if (row_chord(gd, P, rho, y, z, x0, x1)) {
 				const uint32_t rb = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
@@ -635,8 +660,11 @@ __global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uin
 // the wave's (LDS atomics), and the control flow of the selection is wave-uniform.  Same passes, same
 // bins, same tie rule (photons at the k-th distance are taken in walk order) as the per-lane kernel;
 // only the order of the floating-point sum differs (lane partial sums, then a butterfly).
+#ifndef RT_GATHER_WAVES
+#define RT_GATHER_WAVES 4
+#endif
 template <bool SHELL>
-__global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES, RT_GATHER_WAVES))) void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                            const float4* __restrict__ pos,
                                                            const float4* __restrict__ payload, int64_t nph,
                                                            const float* __restrict__ qpos, const float* __restrict__ qnrm,
@@ -687,6 +715,10 @@ __global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const ui
 			wave_shell_sweep<true>(gd, cell_start, pos, P, radius, r2, max_dist2, nc_l, mx_l, bound_l);
 			max_dist2 = wave_max_f(mx_l);
 		}
+#if defined(RT_GATHER_STOP) && RT_GATHER_STOP == 1
+		if (lane == 0) st3(rgb + 3 * (size_t)i, mk3((float)nc, max_dist2, 0));
+		continue;
+#endif
 		uint32_t tau = 0xFFFFFFFFu;
 		int take_equal = 0x7fffffff;
 		float rho_sel = radius;
@@ -785,6 +817,10 @@ __global__ __launch_bounds__(64) void k_photon_gather_wave(GridDesc gd, const ui
 				take_equal = need - wave_sum_i(less);
 			}
 		}
+#if defined(RT_GATHER_STOP) && RT_GATHER_STOP == 2
+		if (lane == 0) st3(rgb + 3 * (size_t)i, mk3((float)nc, max_dist2, __uint_as_float(tau)));
+		continue;
+#endif
 		// pass 3
 		f3 result = mk3(0, 0, 0);
 		if (nc > 0) {
@@ -980,7 +1016,7 @@ int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 	// only the boundary shell is read, and the selection passes read a neighbourhood as small as the k-th distance.
 	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius * 0.5f, (double)(1 << 22), ctx->d_photons, ctx->d_photon_sorted, ctx->d_cell_start,
 	                        ctx->photon_grid_dim, &ctx->photon_cell));
-	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius * 0.125f, (double)(1 << 25), ctx->d_photons_f, ctx->d_photon_sorted_f,
+	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius / (float)ctx->tuning.gather_fine_cells, (double)(1 << 26), ctx->d_photons_f, ctx->d_photon_sorted_f,
 	                        ctx->d_cell_start_f, ctx->photon_grid_dim_f, &ctx->photon_cell_f));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	ctx->num_photons = n;

@@ -93,6 +93,7 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->extra_lds_bytes = env_int("RT_HIP_EXTRA_LDS", 0);
 	t->gather_fine = env_int("RT_HIP_GATHER_FINE", 1);
 	t->gather_xcd_chunk = env_int("RT_HIP_GATHER_XCD_CHUNK", 1024);
+	t->gather_fine_cells = env_int("RT_HIP_GATHER_FINE_CELLS", 8);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
@@ -112,6 +113,7 @@ void rt_clamp_tuning(rt_hip_ctx* ctx)
 	t.frame_sync = t.frame_sync ? 1 : 0;
 	t.gather_fine = t.gather_fine ? 1 : 0;
 	t.gather_xcd_chunk = std::min(8192, std::max(0, t.gather_xcd_chunk));
+	t.gather_fine_cells = std::min(32, std::max(2, t.gather_fine_cells));
 	t.extra_lds_bytes = std::min(64 * 1024, std::max(0, t.extra_lds_bytes));
 	t.max_bvh_depth = std::min(95, std::max(1, t.max_bvh_depth));
 	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;

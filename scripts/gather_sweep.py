@@ -26,6 +26,8 @@ for spec in sys.argv[2:]:
             k, v = item.split("=")
             kw[k] = type(base[k])(float(v))
     g.set_tuning(**kw)
+    if "gather_fine_cells" in spec:
+        n = build_photon_map(g, per_light, len(sc.lights), "cuda")   # the grid is built when the set is installed
     g.radiance_estimate_device(pos, nrm, pos.shape[0], 100, 1.0, out); g.sync()
     g.reset_stats()
     for _ in range(3):
