@@ -56,12 +56,12 @@ GATHER_VISIT_FLOP = 10.0         # per photon visited: 3 sub + 5 (dot) + compare
 GATHER_VISIT_BYTES = 16.0        # position record
 
 
-def kernel_source_hash():
-    """Identity of the kernels a counter profile was taken with: sha256 over the sources of the traversal, frame and
-    gather kernels and their build flags."""
+def kernel_source_hash(photons=False):
+    """Identity of the kernels a counter profile was taken with: sha256 over the sources of the traversal and frame
+    kernels (and of the gather kernels for photon-mapped workloads) and their build flags."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "raytracer_amd", "csrc")
-    for name in ("Makefile", "k_frame.hip", "k_photon.hip", "k_trace.hip", "rt_dev.h", "rt_trace_dev.h"):
+    for name in ("Makefile", "k_frame.hip", "k_trace.hip", "rt_dev.h", "rt_trace_dev.h") + (("k_photon.hip",) if photons else ()):
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
@@ -71,7 +71,7 @@ def offline_counters(workload, shadow_mode, accel, photons):
     """The rocprofv3 --pmc passes of this same command (scripts/profile_round.sh writes the summary; counters
     cannot be read from inside the process being measured).  Returned only when the profile was taken on the
     same workload, builder and kernel sources; otherwise (None, why)."""
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for name in (("r2_pmc_traffic_c5.json",) if photons else ("r2_pmc_traffic.json", "r1_pmc_traffic.json")):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -81,8 +81,8 @@ def offline_counters(workload, shadow_mode, accel, photons):
         have = dict(workload=c.get("workload"), shadows=c.get("shadows", "corrected"), accel=c.get("accel", "ploc"))
         if want != have:
             return None, "profiles/%s is for %s, this run is %s" % (name, have, want)
-        if c.get("kernel_source_hash") != kernel_source_hash():
-            return None, "profiles/%s was taken with other kernel sources (%s, now %s)" % (name, c.get("kernel_source_hash"), kernel_source_hash())
+        if c.get("kernel_source_hash") != kernel_source_hash(photons):
+            return None, "profiles/%s was taken with other kernel sources (%s, now %s)" % (name, c.get("kernel_source_hash"), kernel_source_hash(photons))
         c["file"] = "profiles/" + name
         return c, "offline: rocprofv3 --pmc passes of this command, same workload / builder / kernel sources (%s)" % c["file"]
     return None, "no counter profile committed"

@@ -16,7 +16,7 @@ for line in open(summary):
 from bench import kernel_source_hash
 SIMDS, TAS, XCDS = 1024, 256, 8
 out = {"kernel": kernel, "workload": workload, "shadows": shadows, "accel": accel, "command": command,
-       "kernel_source_hash": kernel_source_hash(),
+       "kernel_source_hash": kernel_source_hash("+photons" in workload),
        "counters_mean_per_launch": vals,
        "correction": "MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports half the bytes of 16 B/lane loads (the node, "
                      "triangle and photon fetches are 16 B/lane) -> x2; WRITE_SIZE as read; unit KB"}
