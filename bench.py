@@ -108,6 +108,7 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=1,
                     help="N = 1 only: frames in flight = contexts (each its own stream) fed from as many host threads; the "
                          "default 1 keeps the kernels of a frame alone on the GPU, which is what the roofline object measures")
+    ap.add_argument("--tuning", default="", help="rt_hip_tuning overrides, name=value,name=value (variant measurements; results never depend on them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra figures (host-to-host and with-rebuild ms/frame, literal shadows, the 1M-triangle target config)")
@@ -180,6 +181,14 @@ def main():
     g = rt.RtHip(scene, semantics="array", accel=ACCEL[args.accel], device=dev_index, profile=1, bounces=2, do_shadows=1,
                  shadow_t_max=shadow_t_max, use_photon_map=1 if args.photons > 0 else 0, photon_estimate=100,
                  photon_radius=1.0, seed=42)
+    tuning = {}
+    for item in filter(None, args.tuning.split(",")):
+        k, v = item.split("=")
+        tuning[k] = type(g.tuning()[k])(float(v))
+    if tuning:
+        g.set_tuning(**tuning)
+        g.invalidate()
+        g.update()
     build_stats = g.stats()
     photon_info = None
     if args.photons > 0:
@@ -270,7 +279,22 @@ def main():
                       profile=0, bounces=2, do_shadows=1, shadow_t_max=shadow_t_max, seed=42)
         extra.append((ge, [torch.zeros(npix * 4, dtype=torch.uint8, device=dev)]))
 
+    # N = 1: frames go through the library's pipeline (rt_hip_frame_enqueue_device / rt_hip_frame_finish): frame k + 1 is
+    # queued before frame k's counters are read back, so the host's per-frame work runs under the GPU's.  Every frame is
+    # still rendered whole and in order; BENCH_PIPELINE=0 takes the call-per-frame entry instead.
+    pipelined = world == 1 and args.photons == 0 and os.environ.get("BENCH_PIPELINE", "1") != "0"
+    enqueue = rt.RtHip.frame_enqueue_device.__wrapped__
+
     def run_steps(count):
+        if not extra and pipelined:
+            total, rays = count * K, 0
+            if total == 0:
+                return 0
+            enqueue(g, gb_p[0], gb_n[0], W, H, tiles[0])
+            for _ in range(total - 1):
+                enqueue(g, gb_p[0], gb_n[0], W, H, tiles[0])
+                rays += g.frame_finish()
+            return rays + g.frame_finish()
         if not extra:
             return sum(step() for _ in range(count))
         import threading
@@ -345,7 +369,9 @@ def main():
             "config": {"workload": args.workload + ("+photons" if args.photons > 0 else ""), "scene": scene.name, "triangles": scene.num_tris, "width": W, "height": H,
                        "frames_per_step": K * nframes, "tile": 64, "bounces": 2, "lights": len(scene.lights),
                        "shadows": args.shadow_mode, "accel": args.accel, "parallelism": "tiles x%d" % world,
+                       **({"tuning": tuning} if tuning else {}),
                        **({"frames_in_flight": inflight} if inflight > 1 else {}),
+                       **({"frame_pipeline": "rt_hip_frame_enqueue_device / rt_hip_frame_finish, one frame queued ahead"} if (pipelined and inflight == 1) else {}),
                        "rays_per_frame": round(total_rays / frames_done, 1),
                        "ms_per_frame": round(ms_per_frame, 4),
                        "frame_latency_ms": round(latency, 4),

@@ -352,6 +352,16 @@ int rt_hip_pack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_frame_rgba, int w
                              const int* d_tile_list, int ntiles, uint8_t* d_packed);
 int rt_hip_unpack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_packed, int width, int height, int tile,
                                const int* d_tile_list, int ntiles, uint8_t* d_frame_rgba);
+/* The same frame as rt_hip_render_frame_device, in a pipeline: rt_hip_frame_enqueue_device queues all of the frame's kernels
+ * and returns WITHOUT waiting; rt_hip_frame_finish waits for the OLDEST enqueued frame (its image is then complete) and
+ * returns its secondary-ray count.  At most two frames may be enqueued and unfinished; with one enqueued ahead the host's
+ * per-frame work runs under the previous frame's kernels.  Frames are executed in order on the context's stream; the other
+ * frame entries (rt_hip_render_frame*, rt_hip_render_tiles*) refuse to run while frames are enqueued (RT_HIP_ERR_STATE).  Frames the sync-free driver
+ * does not take (photon map, > 30 lights, too large) are rendered inside the enqueue call.  No counterpart in the reference,
+ * whose frame loop is strictly sequential (data/scene.cpp:40-58). */
+int rt_hip_frame_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width, int height,
+                                uint8_t* d_rgba_out);
+int rt_hip_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays);
 /* Secondary rays issued by the last frame call (shadow + reflection + refraction). */
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx);
 

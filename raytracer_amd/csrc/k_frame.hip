@@ -1314,10 +1314,10 @@ static int owned_tile_list(rt_hip_ctx* ctx, int w, int h, int tile, int rank, in
 	return RT_HIP_OK;
 }
 
-static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int tile, int rank, int nranks,
-                              bool* overflowed, bool* declined)
+// Queue every kernel of the frame and the read-back of its counters into pf->h_fc; nothing is waited for.
+static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int tile, int rank, int nranks, PendingFrame* pf,
+                               bool* declined)
 {
-	*overflowed = false;
 	*declined = true;
 	hipStream_t st = ctx->stream;
 	SceneView sv = rt_scene_view(ctx);
@@ -1333,7 +1333,9 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	if (packed && !fs.packed) { rt_set_error("packed tile output needs nranks > 1 and a tile size that is a multiple of 8"); return RT_HIP_ERR_ARG; }
 	if ((int64_t)fs.per_frame * fs.nframes > FRAME_LEVEL_CAP) return RT_HIP_OK;
 	const int n0 = fs.per_frame * fs.nframes;
-	if (n0 == 0) { *declined = false; return RT_HIP_OK; }  // this rank owns no tile
+	pf->n0 = n0; pf->bounces = bounces; pf->nframes = fs.nframes; pf->num_lights = sv.num_lights; pf->rays = 0;
+	pf->trace_mark = ctx->trace_events_used;
+	if (n0 == 0) { *declined = false; pf->complete = true; return RT_HIP_OK; }  // this rank owns no tile
 	std::vector<int64_t> cap(bounces), off(bounces + 1, 0);
 	for (int L = 0; L < bounces; ++L) {
 		cap[L] = L == 0 ? n0 : std::min<int64_t>(2 * cap[L - 1], FRAME_LEVEL_CAP);
@@ -1394,7 +1396,9 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		RT_HIP_CHECK(hipGetLastError());
 		return RT_HIP_OK;
 	};
-	RT_HIP_CHECK(hipEventRecord(ctx->ev0, st));
+	pf->shadows = shadows;
+	pf->complete = false;
+	RT_HIP_CHECK(hipEventRecord(pf->ev0, st));
 	// The counters are zeroed at the END of a frame, behind its read-back, for the frame that follows: the
 	// first thing a frame queues is then its first kernel, not a fill and the host time after it.
 	if (ctx->fcount_clean != fc || ctx->fcount_clean_n < nfc) RT_HIP_CHECK(hipMemsetAsync(fc, 0, (size_t)nfc * 4, st));
@@ -1464,38 +1468,62 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 		                   pshade, fs, fs.packed ? fs.per_frame : w * h, (float*)nullptr, 1, occl, level_uv(L));
 		RT_HIP_CHECK(hipGetLastError());
 	}
-	int* h_fc = (int*)ctx->h_small;  // 4 KiB pinned; nfc <= 80 ints
-	RT_HIP_CHECK(hipMemcpyAsync(h_fc, fc, (size_t)nfc * 4, hipMemcpyDeviceToHost, st));
-	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));
+	RT_HIP_CHECK(hipMemcpyAsync(pf->h_fc, fc, (size_t)nfc * 4, hipMemcpyDeviceToHost, st));  // 512 B pinned per slot; nfc <= 80 ints
+	RT_HIP_CHECK(hipEventRecord(pf->ev1, st));
 	hipLaunchKernelGGL(k_zero_ints, dim3(1), dim3(128), 0, st, fc, nfc);  // behind the event: for the next frame
 	RT_HIP_CHECK(hipGetLastError());
 	ctx->fcount_clean = fc; ctx->fcount_clean_n = nfc;
-	RT_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+	pf->trace_mark = ctx->trace_events_used;
+	return RT_HIP_OK;
+}
+
+// Wait for the frame's counters and account for it.  *overflowed: a level needed more than its bound, the frame has to be
+// rendered again with host-sized levels.
+static int frame_async_finish(rt_hip_ctx* ctx, PendingFrame* pf, bool* overflowed)
+{
+	*overflowed = false;
+	if (pf->complete) { ctx->last_frame_rays = pf->rays; return RT_HIP_OK; }
+	RT_HIP_CHECK(hipEventSynchronize(pf->ev1));
+	const int* h_fc = pf->h_fc;
 	if (h_fc[1]) {
 		*overflowed = true;
-		ctx->trace_events_used = 0;  // the frame is rendered again; drop this attempt's timings
+		// the frame is rendered again; this attempt's launch timings are folded in as they are (rare path)
+		RT_CHECK(rt_collect_timing(ctx, pf->trace_mark));
 		return RT_HIP_OK;
 	}
 	int64_t rays_any = 0, rays_closest = 0;
 	int levels = 0;
-	for (int L = 0; L < bounces; ++L) {
-		const int nL = L == 0 ? n0 : h_fc[8 + 8 * L];
+	for (int L = 0; L < pf->bounces; ++L) {
+		const int nL = L == 0 ? pf->n0 : h_fc[8 + 8 * L];
 		if (nL == 0) break;
 		levels = L + 1;
-		if (shadows) rays_any += (int64_t)(L == 0 ? h_fc[0] : nL) * sv.num_lights;
+		if (pf->shadows) rays_any += (int64_t)(L == 0 ? h_fc[0] : nL) * pf->num_lights;
 		rays_closest += (int64_t)h_fc[8 + 8 * L + 1] + h_fc[8 + 8 * L + 2];
 	}
 	ctx->stats.rays_any += rays_any;
 	ctx->stats.rays_closest += rays_closest;
 	float ms = 0;
-	RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+	RT_HIP_CHECK(hipEventElapsedTime(&ms, pf->ev0, pf->ev1));
 	ctx->stats.frame_ms += ms;
-	ctx->stats.frames += fs.nframes;
-	ctx->last_frame_rays = rays_any + rays_closest;
+	ctx->stats.frames += pf->nframes;
+	pf->rays = rays_any + rays_closest;
+	ctx->last_frame_rays = pf->rays;
 	ctx->last_count = levels;
-	RT_CHECK(rt_collect_timing(ctx));
+	RT_CHECK(rt_collect_timing(ctx, pf->trace_mark));
 	return RT_HIP_OK;
 }
+
+static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int tile, int rank, int nranks,
+                              bool* overflowed, bool* declined)
+{
+	*overflowed = false;
+	if (ctx->pending_count > 0) { rt_set_error("%d frame(s) are enqueued: rt_hip_frame_finish() them first", ctx->pending_count); return RT_HIP_ERR_STATE; }
+	PendingFrame* pf = &ctx->pending[0];
+	RT_CHECK(frame_async_enqueue(ctx, fs, w, h, tile, rank, nranks, pf, declined));
+	if (*declined) return RT_HIP_OK;
+	return frame_async_finish(ctx, pf, overflowed);
+}
+
 
 static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, const float* d_uv, int w, int h,
                              int tile, int rank, int nranks, uint8_t* d_rgba);
@@ -1727,5 +1755,57 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 	// stash per-level counts for the census
 	ctx->last_count = levels;
 	RT_CHECK(rt_collect_timing(ctx));
+	return RT_HIP_OK;
+}
+
+// ---- the frame pipeline ------------------------------------------------------------------------------
+// rt_hip_frame_enqueue_device queues a whole frame and returns without waiting for it; rt_hip_frame_finish waits for the
+// OLDEST enqueued frame and accounts for it.  With one frame enqueued ahead, the host's per-frame work (reading the
+// counters, returning to the caller, queueing the next dozen launches: ~55 us) runs under the previous frame's kernels.
+int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba)
+{
+	if (ctx->pending_count >= 2) { rt_set_error("two frames are already enqueued: rt_hip_frame_finish() one first"); return RT_HIP_ERR_STATE; }
+	if (ctx->cfg.bounces <= 0 || ctx->cfg.bounces > 8) { rt_set_error("bounces must be 1..8"); return RT_HIP_ERR_LIMIT; }
+	if ((int)ctx->lights.size() > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
+	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 26) { rt_set_error("frame larger than 2^26 texels"); return RT_HIP_ERR_LIMIT; }
+	PendingFrame* pf = &ctx->pending[(ctx->pending_head + ctx->pending_count) & 1];
+	FrameSet fs;
+	memset(&fs, 0, sizeof(fs));
+	fs.nframes = 1;
+	fs.pos[0] = d_pos_rgb; fs.nrm[0] = d_nrm_rgba; fs.rgba[0] = d_rgba;
+	fs.uv[0] = ctx->frame_uv_count > 0 ? ctx->frame_uv[0] : nullptr;
+	pf->fs = fs; pf->w = w; pf->h = h; pf->tile = 64; pf->rank = 0; pf->nranks = 1; pf->packed = 0;
+	bool declined = true;
+	const bool can_async = !ctx->cfg.use_photon_map && !ctx->tuning.frame_sync && (int)ctx->lights.size() <= FRAME_ASYNC_MAX_LIGHTS;
+	if (can_async) RT_CHECK(frame_async_enqueue(ctx, fs, w, h, 64, 0, 1, pf, &declined));
+	if (declined) {
+		// photon-mapped frames, more than 30 lights, frames too large to size by bounds: rendered here and now
+		if (ctx->pending_count > 0) { rt_set_error("this frame needs the synchronous driver: finish the enqueued frame first"); return RT_HIP_ERR_STATE; }
+		RT_CHECK(render_frame_sync(ctx, d_pos_rgb, d_nrm_rgba, fs.uv[0], w, h, 64, 0, 1, d_rgba));
+		pf->complete = true;
+		pf->rays = ctx->last_frame_rays;
+	}
+	pf->used = true;
+	++ctx->pending_count;
+	return RT_HIP_OK;
+}
+
+int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
+{
+	if (out_rays) *out_rays = 0;
+	if (ctx->pending_count == 0) { rt_set_error("no frame is enqueued"); return RT_HIP_ERR_STATE; }
+	PendingFrame* pf = &ctx->pending[ctx->pending_head];
+	bool overflowed = false;
+	RT_CHECK(frame_async_finish(ctx, pf, &overflowed));
+	if (overflowed) {
+		// exceptional: the frame again, on the driver that sizes every level on the host (behind whatever is still queued)
+		RT_CHECK(render_frame_sync(ctx, pf->fs.pos[0], pf->fs.nrm[0], pf->fs.uv[0], pf->w, pf->h, pf->tile, pf->rank, pf->nranks, pf->fs.rgba[0]));
+		pf->rays = ctx->last_frame_rays;
+	}
+	if (out_rays) *out_rays = pf->rays;
+	ctx->last_frame_rays = pf->rays;
+	pf->used = false;
+	ctx->pending_head ^= 1;
+	--ctx->pending_count;
 	return RT_HIP_OK;
 }

@@ -232,10 +232,11 @@ unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls)
 }
 
 // Fold the pending event pairs into stats (requires the stream to be idle or syncs on the events).
-int rt_collect_timing(rt_hip_ctx* ctx)
+int rt_collect_timing(rt_hip_ctx* ctx, size_t upto)
 {
-	if (!ctx->cfg.profile) ctx->trace_events_used = 0;
-	for (size_t i = 0; i < ctx->trace_events_used; ++i) {
+	if (!ctx->cfg.profile) ctx->trace_events_used = ctx->trace_events_collected = 0;
+	const size_t end = std::min(upto, ctx->trace_events_used);
+	for (size_t i = ctx->trace_events_collected; i < end; ++i) {
 		RT_HIP_CHECK(hipEventSynchronize(ctx->trace_events[i].second));
 		float ms = 0;
 		RT_HIP_CHECK(hipEventElapsedTime(&ms, ctx->trace_events[i].first, ctx->trace_events[i].second));
@@ -243,7 +244,8 @@ int rt_collect_timing(rt_hip_ctx* ctx)
 		else if (ctx->trace_event_class[i]) ctx->stats.any_ms += ms;
 		else ctx->stats.closest_ms += ms;
 	}
-	ctx->trace_events_used = 0;
+	ctx->trace_events_collected = std::max(ctx->trace_events_collected, end);
+	if (ctx->trace_events_collected >= ctx->trace_events_used) ctx->trace_events_used = ctx->trace_events_collected = 0;
 	if (ctx->cfg.census && ctx->d_census.p) {
 		unsigned long long c[7];
 		RT_HIP_CHECK(hipMemcpy(c, ctx->d_census.p, sizeof(c), hipMemcpyDeviceToHost));
@@ -344,6 +346,12 @@ int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out)
 	if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
 	if (e == hipSuccess) e = hipHostMalloc(&ctx->h_small, 4096, hipHostMallocDefault);
+	if (e == hipSuccess) e = hipHostMalloc(&ctx->h_pipe, 1024, hipHostMallocDefault);
+	for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+		ctx->pending[k].h_fc = (int*)((char*)ctx->h_pipe + 512 * k);
+		e = hipEventCreate(&ctx->pending[k].ev0);
+		if (e == hipSuccess) e = hipEventCreate(&ctx->pending[k].ev1);
+	}
 	if (e != hipSuccess) {
 		rt_set_error("context creation failed: %s", hipGetErrorString(e));
 		delete ctx;
@@ -375,6 +383,11 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	if (ctx->h_records) (void)hipHostFree(ctx->h_records);
 	if (ctx->h_offsets) (void)hipHostFree(ctx->h_offsets);
 	if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+	if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
+	for (int k = 0; k < 2; ++k) {
+		if (ctx->pending[k].ev0) (void)hipEventDestroy(ctx->pending[k].ev0);
+		if (ctx->pending[k].ev1) (void)hipEventDestroy(ctx->pending[k].ev1);
+	}
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -883,6 +896,20 @@ int rt_hip_render_frame(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float*
 	RT_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_offsets.p, npix * 4, hipMemcpyDeviceToHost, st));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	return RT_HIP_OK;
+}
+
+int rt_hip_frame_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width, int height,
+                                uint8_t* d_rgba_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_rgba_out) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	return rt_frame_enqueue(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, d_rgba_out);
+}
+
+int rt_hip_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
+{
+	RT_CHECK(check_ctx(ctx));
+	return rt_frame_finish(ctx, out_rays);
 }
 
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx) { return ctx ? ctx->last_frame_rays : 0; }

@@ -103,6 +103,21 @@ struct FrameSet {
 	int packed;            // 1: rgba[f] is the PACKED chunk of the rank's tiles (tile after tile, row-major inside), not a frame
 };
 
+// A frame whose kernels are queued and whose counters the host has not read yet (sync-free frame driver).
+struct PendingFrame {
+	bool used = false;
+	bool complete = false;       // rendered synchronously at enqueue (the sync-free driver declined it): nothing to wait for
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	int* h_fc = nullptr;         // pinned: the frame's counters land here
+	size_t trace_mark = 0;       // trace_events index behind this frame's launches
+	int n0 = 0, bounces = 0, nframes = 0, num_lights = 0;
+	bool shadows = false;
+	int64_t rays = 0;
+	// what a repeat on the synchronous driver needs (a level overflowed its bound)
+	FrameSet fs;
+	int w = 0, h = 0, tile = 0, rank = 0, nranks = 1, packed = 0;
+};
+
 struct rt_hip_ctx {
 	rt_hip_config cfg;
 	rt_hip_tuning tuning;
@@ -111,6 +126,10 @@ struct rt_hip_ctx {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> trace_events;  // pending (profile mode)
 	std::vector<int> trace_event_class;                           // 0 closest, 1 any
 	size_t trace_events_used = 0;
+	size_t trace_events_collected = 0;                            // [collected, used) are still to be folded into the stats
+	PendingFrame pending[2];                                      // the frame pipeline (rt_hip_frame_enqueue_device / _finish)
+	int pending_head = 0, pending_count = 0;                      // oldest slot, frames enqueued and not finished
+	void* h_pipe = nullptr;                                       // pinned: 2 x 512 B of frame counters
 	DevBuf d_census, d_spill, d_tile_list;
 	int tile_key[5] = {0, 0, 0, 0, 0};                            // (w, h, tile, rank, nranks) of d_tile_list
 	int tile_count = 0;
@@ -192,7 +211,7 @@ int rt_begin_trace_timing(rt_hip_ctx* ctx, hipStream_t st = nullptr);  // nullpt
 int rt_end_trace_timing(rt_hip_ctx* ctx, int cls, hipStream_t st = nullptr);
 int rt_next_trace_events(rt_hip_ctx* ctx, int cls, hipEvent_t* a, hipEvent_t* b);  // for hipExtLaunchKernelGGL
 unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls);  // nullptr unless cfg.census
-int rt_collect_timing(rt_hip_ctx* ctx);
+int rt_collect_timing(rt_hip_ctx* ctx, size_t upto = (size_t)-1);  // fold the event pairs [collected, min(upto, used))
 int rt_ensure_pinned(void** p, size_t* cap, size_t bytes);
 
 // ---- k_geometry.hip ------------------------------------------------------------------------------
@@ -235,6 +254,8 @@ int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, in
 int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb, float* d_uv = nullptr);
 int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
                     int rank, int nranks, uint8_t* d_rgba);
+int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba);
+int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays);
 int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
                      int h, int tile, int rank, int nranks, uint8_t* const* d_rgba, int packed = 0);
 int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int w, int h, int tile, int nranks,
