@@ -296,12 +296,15 @@ __device__ __forceinline__ int row_div(int row, int ny, uint32_t magic, bool sma
 // their lengths across the lanes, then element e of the concatenation belongs to the run found by a 6-step binary
 // search over the lanes' prefix sums (shuffles) -- and read 256 elements per round, whatever run they belong to.
 // visit(q, slot, active) runs in wave-uniform control flow.
+#ifndef RT_GATHER_LONG
+#define RT_GATHER_LONG 256u
+#endif
 template <typename V>
 __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, uint32_t r0, uint32_t r1, V visit)
 {
 	const int lane = lane_id();
 	uint32_t len = r1 > r0 ? r1 - r0 : 0u;
-	uint64_t longm = __ballot(len >= 256u);
+	uint64_t longm = __ballot(len >= RT_GATHER_LONG);
 	while (longm) {
 		const int src = __ffsll((unsigned long long)longm) - 1;
 		longm &= longm - 1;
@@ -318,7 +321,7 @@ __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, 
 			visit(q, s + lane, act);
 		}
 	}
-	if (len >= 256u) len = 0u;
+	if (len >= RT_GATHER_LONG) len = 0u;
 	uint32_t end = len;   // inclusive prefix sum over the lanes
 	for (int off = 1; off < 64; off <<= 1) {
 		const uint32_t y = __shfl_up(end, off);
@@ -477,8 +480,12 @@ __device__ __forceinline__ void wave_shell_sweep(const GridDesc& gd, const uint3
 			const float l2 = dot3(d, d);
 			if (act && l2 < r2) { if (!SECOND) ++nc_l; mx_l = fmaxf(mx_l, l2); }
 		};
+#ifndef RT_GATHER_NOVISIT   // probe builds: the row tables alone
 		wave_visit_runs(pos, a0, a1, visit);
 		if (__ballot(b1 > b0)) wave_visit_runs(pos, b0, b1, visit);
+#else
+		(void)visit;
+#endif
 	}
 }
 
