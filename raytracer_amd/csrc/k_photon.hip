@@ -289,6 +289,12 @@ __device__ __forceinline__ int row_div(int row, int ny, uint32_t magic, bool sma
 	return small ? (int)__umulhi((uint32_t)row, magic) : row / ny;
 }
 
+__device__ __forceinline__ uint32_t wave_sum_u(uint32_t v)
+{
+	for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+	return v;
+}
+
 // The wave visits every sorted slot of 64 runs [r0, r1), one run held per lane (empty: r1 <= r0).  A point's
 // neighbourhood is many short runs (one per grid row) and a wave that reads them one after the other waits one memory
 // round trip per run -- that, not the bytes, bounded the gather (~140 us per point).  So: runs of 256 slots and more
@@ -299,12 +305,21 @@ __device__ __forceinline__ int row_div(int row, int ny, uint32_t magic, bool sma
 #ifndef RT_GATHER_LONG
 #define RT_GATHER_LONG 256u
 #endif
+#ifdef RT_GATHER_PROBE   // probe builds: what the calls of wave_visit_runs are made of (scripts/gather_sweep.py prints it)
+__device__ unsigned long long g_gather_probe[16];
+#define RT_PROBE_ADD(i, v) do { const unsigned long long v__ = (unsigned long long)(v); if (lane_id() == 0) atomicAdd(&g_gather_probe[i], v__); } while (0)
+#else
+#define RT_PROBE_ADD(i, v) do {} while (0)
+#endif
 template <typename V>
 __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, uint32_t r0, uint32_t r1, V visit)
 {
 	const int lane = lane_id();
 	uint32_t len = r1 > r0 ? r1 - r0 : 0u;
 	uint64_t longm = __ballot(len >= RT_GATHER_LONG);
+	RT_PROBE_ADD(0, 1);
+	RT_PROBE_ADD(4, __popcll(longm));
+	RT_PROBE_ADD(5, wave_sum_u(len >= RT_GATHER_LONG ? len : 0u));
 	while (longm) {
 		const int src = __ffsll((unsigned long long)longm) - 1;
 		longm &= longm - 1;
@@ -315,9 +330,10 @@ __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, 
 			visit(qa, s + lane, true); visit(qb, s + 64 + lane, true); visit(qc, s + 128 + lane, true); visit(qd, s + 192 + lane, true);
 		}
 		for (; s < b; s += 64) {
+			// padding lanes re-read the run's last slot: a load under a branch is waited for at once, and the
+			// loads of this loop would queue up behind each other's memory round trips
 			const bool act = s + lane < b;
-			float4 q = make_float4(0, 0, 0, 0);
-			if (act) q = pos[s + lane];
+			const float4 q = pos[act ? s + lane : b - 1];
 			visit(q, s + lane, act);
 		}
 	}
@@ -328,10 +344,15 @@ __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, 
 		if (lane >= off) end += y;
 	}
 	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
+	RT_PROBE_ADD(1, total > 0u);
+	RT_PROBE_ADD(2, (total + 255u) / 256u);
+	RT_PROBE_ADD(3, total);
+	RT_PROBE_ADD(6, __popcll(__ballot(len > 0u)));
 	const uint32_t base = r0 - (end - len);   // slot of flattened element e inside this lane's run = base + e
 	// Each lane takes FOUR consecutive elements of the concatenation per round: one binary search for the first, and the
 	// run of each next element is the same one or the next non-empty one (one shuffle to find out).
 	const uint64_t nonempty = __ballot(len > 0u);
+	const uint32_t first_slot = nonempty ? (uint32_t)__builtin_amdgcn_readlane((int)r0, __ffsll((unsigned long long)nonempty) - 1) : 0u;
 	for (uint32_t e0 = 0; e0 < total; e0 += 256) {
 		float4 q[4];
 		uint32_t slot[4];
@@ -354,8 +375,8 @@ __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, 
 				}
 			}
 			slot[k] = __shfl(base, j) + ek;
-			q[k] = make_float4(0, 0, 0, 0);
-			if (act[k]) q[k] = pos[slot[k]];
+			// unconditional (see above): the four loads are in flight together; padding lanes read the run's first slot
+			q[k] = pos[act[k] ? slot[k] : first_slot];
 		}
 #pragma unroll
 		for (int k = 0; k < 4; ++k) visit(q[k], slot[k], act[k]);
@@ -478,7 +499,11 @@ __device__ __forceinline__ void wave_shell_sweep(const GridDesc& gd, const uint3
 		auto visit = [&](const float4 q, uint32_t, bool act) {
 			const f3 d = mk3(q.x, q.y, q.z) - P;
 			const float l2 = dot3(d, d);
-			if (act && l2 < r2) { if (!SECOND) ++nc_l; mx_l = fmaxf(mx_l, l2); }
+			// branch-free, and the maximum taken on the bit patterns (l2 >= 0): fmaxf costs two canonicalising
+			// v_max more per photon
+			const bool in = act && l2 < r2;
+			if (!SECOND) nc_l += in ? 1 : 0;
+			mx_l = __uint_as_float(max(__float_as_uint(mx_l), in ? __float_as_uint(l2) : 0u));
 		};
 #ifndef RT_GATHER_NOVISIT   // probe builds: the row tables alone
 		wave_visit_runs(pos, a0, a1, visit);
@@ -670,14 +695,30 @@ __global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uin
 #ifndef RT_GATHER_WAVES
 #define RT_GATHER_WAVES 4
 #endif
-template <bool SHELL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES, RT_GATHER_WAVES))) void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
+// PHASE 1: pass 1 alone, (count, max_dist2) per queue entry into `p1`; PHASE 2: the selection and the sum, pass 1's
+// results read back; PHASE 0: everything in one kernel.  Two kernels because fused the kernel holds the live state of
+// both halves (it spilled ~100 VGPRs and 220 SGPRs at 4 waves/SIMD), and the two halves want different occupancies:
+// pass 1 streams photons, the selection is a chain of short dependent sweeps.
+#ifndef RT_GATHER_WAVES1
+#define RT_GATHER_WAVES1 RT_GATHER_WAVES
+#endif
+#ifndef RT_GATHER_WAVES2
+#define RT_GATHER_WAVES2 RT_GATHER_WAVES
+#endif
+#ifndef RT_GATHER_P1_WAVES   // waves per workgroup of the PHASE 1 kernel: consecutive queue entries side by side on one CU
+#define RT_GATHER_P1_WAVES 4
+#endif
+template <bool SHELL, int PHASE>
+__global__ __launch_bounds__(PHASE == 1 ? 64 * RT_GATHER_P1_WAVES : 64) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ? RT_GATHER_WAVES1 : PHASE == 2 ? RT_GATHER_WAVES2 : RT_GATHER_WAVES,
+                                                                    PHASE == 1 ? RT_GATHER_WAVES1 : PHASE == 2 ? RT_GATHER_WAVES2 : RT_GATHER_WAVES)))
+void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                            const float4* __restrict__ pos,
                                                            const float4* __restrict__ payload, int64_t nph,
                                                            const float* __restrict__ qpos, const float* __restrict__ qnrm,
                                                            const int* __restrict__ heavy_queue,
                                                            const int* __restrict__ heavy_count, int count, float radius,
-                                                           GatherConst gc, float* __restrict__ rgb, int xcd_chunk)
+                                                           GatherConst gc, float* __restrict__ rgb, int xcd_chunk,
+                                                           float2* __restrict__ p1)
 {
 	__shared__ uint32_t s_hist[SEL_BINS];
 	__shared__ uint32_t s_list[SEL_LIST];
@@ -690,7 +731,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_GATHER_WA
 	// XCD-aware order (rt_trace_dev.h: xcd_block_index): XCD x takes `xcd_chunk` consecutive queue entries of every
 	// group of 8 * xcd_chunk.  Queue order is screen order, neighbouring points read nearly the same photons, and the
 	// heavy points are bound by the bandwidth those reads get: this way they come from the XCD's own L2.
-	for (int h = (int)xcd_block_index(xcd_chunk); h < nheavy; h += gridDim.x) {
+	// PHASE 1 runs several waves per workgroup, each on a point of its own: neighbours in the queue, hence in the frame,
+	// read the same photons at the same time through one L1
+	const int nw = PHASE == 1 ? RT_GATHER_P1_WAVES : 1, wv = PHASE == 1 ? (int)(threadIdx.x >> 6) : 0;
+	for (int h = (int)xcd_block_index(xcd_chunk) * nw + wv; h < nheavy; h += gridDim.x * nw) {
 		const int i = __builtin_amdgcn_readfirstlane(heavy_queue[h]);
 		f3 P, N;
 		P.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 0])));
@@ -707,20 +751,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_GATHER_WA
 		};
 		// pass 1: the number of photons within the radius and max_dist2 over all of them; interiors are counted
 		// from the cell table, only the boundary shell is read (wave_shell_sweep)
-		int nc_l = 0;
-		float mx_l = 0.0f, bound_l = 0.0f;
-		if (SHELL) {
-			wave_shell_sweep<false>(gd, cell_start, pos, P, radius, r2, 0.0f, nc_l, mx_l, bound_l);
-		} else {
-			for_each_neighbour_wave(gd, cell_start, pos, P, radius, [&](uint32_t, float l2, bool act) {
-				if (act && l2 < r2) { ++nc_l; mx_l = fmaxf(mx_l, l2); }
-			});
-		}
-		const int nc = wave_sum_i(nc_l);
-		float max_dist2 = wave_max_f(mx_l);
-		if (SHELL && wave_max_f(bound_l) > max_dist2) {   // rare: an interior run could hold the farthest candidate
-			wave_shell_sweep<true>(gd, cell_start, pos, P, radius, r2, max_dist2, nc_l, mx_l, bound_l);
+		int nc;
+		float max_dist2;
+		if constexpr (PHASE != 2) {
+			int nc_l = 0;
+			float mx_l = 0.0f, bound_l = 0.0f;
+			if (SHELL) {
+				wave_shell_sweep<false>(gd, cell_start, pos, P, radius, r2, 0.0f, nc_l, mx_l, bound_l);
+			} else {
+				for_each_neighbour_wave(gd, cell_start, pos, P, radius, [&](uint32_t, float l2, bool act) {
+					if (act && l2 < r2) { ++nc_l; mx_l = fmaxf(mx_l, l2); }
+				});
+			}
+			nc = wave_sum_i(nc_l);
 			max_dist2 = wave_max_f(mx_l);
+			if (SHELL && wave_max_f(bound_l) > max_dist2) {   // rare: an interior run could hold the farthest candidate
+				wave_shell_sweep<true>(gd, cell_start, pos, P, radius, r2, max_dist2, nc_l, mx_l, bound_l);
+				max_dist2 = wave_max_f(mx_l);
+			}
+			if constexpr (PHASE == 1) {
+				if (lane == 0) p1[h] = make_float2(__int_as_float(nc), max_dist2);
+				continue;
+			}
+		} else {
+			const float2 r = p1[h];
+			nc = __builtin_amdgcn_readfirstlane(__float_as_int(r.x));
+			max_dist2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r.y)));
 		}
 #if defined(RT_GATHER_STOP) && RT_GATHER_STOP == 1
 		if (lane == 0) st3(rgb + 3 * (size_t)i, mk3((float)nc, max_dist2, 0));
@@ -959,15 +1015,19 @@ int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count,
 
 // One uniform grid over the photon bounds [mn, mx]: cell enlarged until the grid has at most max_cells cells; photons
 // counting-sorted by cell (rows along x are contiguous in the sorted arrays), cell_start by lower bound.
+// One EMPTY cell is added on every side: the border cells of a grid also receive what cell_coord clamps into them, so
+// the gather treats them as reaching to infinity and never as interior to a sphere -- and without the margin the
+// photons on the scene's floor and outer walls, most of them, sit exactly in those cells.
 static int build_one_grid(rt_hip_ctx* ctx, const PhotonRec* ph, int64_t n, const float* mn, const float* mx, float cell,
-                          double max_cells, DevBuf& d_pos, DevBuf& d_payload, DevBuf& d_cell_start, int* dim_out, float* cell_out)
+                          double max_cells, DevBuf& d_pos, DevBuf& d_payload, DevBuf& d_cell_start, int* dim_out, float* cell_out,
+                          float* min_out)
 {
 	hipStream_t st = ctx->stream;
 	int dim[3];
 	for (;;) {
 		double cells = 1;
 		for (int k = 0; k < 3; ++k) {
-			dim[k] = std::max(1, (int)std::floor((mx[k] - mn[k]) / cell) + 1);
+			dim[k] = std::max(1, (int)std::floor((mx[k] - mn[k]) / cell) + 1) + 2;
 			cells *= dim[k];
 		}
 		if (cells <= max_cells) break;
@@ -975,7 +1035,7 @@ static int build_one_grid(rt_hip_ctx* ctx, const PhotonRec* ph, int64_t n, const
 	}
 	const int ncells = dim[0] * dim[1] * dim[2];
 	GridDesc gd;
-	for (int k = 0; k < 3; ++k) { gd.mn[k] = mn[k]; gd.dim[k] = dim[k]; dim_out[k] = dim[k]; }
+	for (int k = 0; k < 3; ++k) { gd.mn[k] = mn[k] - cell; min_out[k] = gd.mn[k]; gd.dim[k] = dim[k]; dim_out[k] = dim[k]; }
 	gd.cell = cell; gd.inv_cell = 1.0f / cell;
 	*cell_out = cell;
 	RT_CHECK(ctx->d_morton.reserve((size_t)n * 8));
@@ -1000,6 +1060,9 @@ static int build_one_grid(rt_hip_ctx* ctx, const PhotonRec* ph, int64_t n, const
 	return RT_HIP_OK;
 }
 
+#ifndef RT_FINE_CELL_CAP_LOG2
+#define RT_FINE_CELL_CAP_LOG2 26
+#endif
 int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 {
 	hipStream_t st = ctx->stream;
@@ -1015,17 +1078,22 @@ int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 	RT_HIP_CHECK(hipMemcpyAsync(ob, ctx->d_bounds.p, sizeof(ob), hipMemcpyDeviceToHost, st));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	float mn[3], mx[3];
-	for (int k = 0; k < 3; ++k) { mn[k] = ord2f(ob[k]); mx[k] = ord2f(ob[3 + k]); ctx->photon_grid_min[k] = mn[k]; }
+	for (int k = 0; k < 3; ++k) { mn[k] = ord2f(ob[k]); mx[k] = ord2f(ob[3 + k]); }
 	const float radius = ctx->cfg.photon_radius > 0.0f ? ctx->cfg.photon_radius : 1.0f;
 	// Two grids over the same photons.  Coarse, cell = radius / 2: what the lane-per-point gather walks (a point with
 	// few photons nearby pays per grid row, so rows must be few).  Fine, cell = radius / 8: what the wave-per-point
 	// gather of the photon-rich points walks -- cells entirely inside the sphere are counted from the cell table and
 	// only the boundary shell is read, and the selection passes read a neighbourhood as small as the k-th distance.
 	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius * 0.5f, (double)(1 << 22), ctx->d_photons, ctx->d_photon_sorted, ctx->d_cell_start,
-	                        ctx->photon_grid_dim, &ctx->photon_cell));
-	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius / (float)ctx->tuning.gather_fine_cells, (double)(1 << 26), ctx->d_photons_f, ctx->d_photon_sorted_f,
-	                        ctx->d_cell_start_f, ctx->photon_grid_dim_f, &ctx->photon_cell_f));
+	                        ctx->photon_grid_dim, &ctx->photon_cell, ctx->photon_grid_min));
+	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius / (float)ctx->tuning.gather_fine_cells, (double)(1ll << RT_FINE_CELL_CAP_LOG2), ctx->d_photons_f, ctx->d_photon_sorted_f,
+	                        ctx->d_cell_start_f, ctx->photon_grid_dim_f, &ctx->photon_cell_f, ctx->photon_grid_min_f));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
+#ifdef RT_GATHER_PROBE
+	fprintf(stderr, "photon grids: bounds [%g %g %g]-[%g %g %g], coarse cell %g (%d x %d x %d), fine cell %g (%d x %d x %d)\n", mn[0], mn[1], mn[2],
+	        mx[0], mx[1], mx[2], ctx->photon_cell, ctx->photon_grid_dim[0], ctx->photon_grid_dim[1], ctx->photon_grid_dim[2], ctx->photon_cell_f,
+	        ctx->photon_grid_dim_f[0], ctx->photon_grid_dim_f[1], ctx->photon_grid_dim_f[2]);
+#endif
 	ctx->num_photons = n;
 	return RT_HIP_OK;
 }
@@ -1047,9 +1115,10 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	// on the device).  tuning.gather_heavy is the threshold (0: every point with a photon nearby takes
 	// the wave kernel; a huge value: none does) -- the parity tests run both extremes.
 	const uint32_t heavy = ctx->tuning.gather_heavy;
-	RT_CHECK(ctx->d_heavy.reserve(((size_t)npts + 16) * sizeof(int)));
+	RT_CHECK(ctx->d_heavy.reserve(((size_t)npts + 16) * sizeof(int) + ((size_t)npts + 1) * sizeof(float2)));
 	int* heavy_count = ctx->d_heavy.as<int>();
 	int* heavy_queue = heavy_count + 16;
+	float2* pass1 = (float2*)(heavy_queue + npts + (npts & 1));   // (count, max_dist2) per queue entry, between the wave kernel's two launches
 	RT_HIP_CHECK(hipMemsetAsync(heavy_count, 0, sizeof(int), ctx->stream));
 	ctx->stats.gather_points += npts;
 	if (unsigned long long* cen = ctx->num_photons > 0 ? rt_census_ptr(ctx, 2) : nullptr) {
@@ -1070,15 +1139,26 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 		const int waves = (std::min(npts, 64 * 1024) + unit - 1) / unit * unit;
 		if (ctx->tuning.gather_fine) {
 			GridDesc gf;
-			for (int k = 0; k < 3; ++k) { gf.mn[k] = ctx->photon_grid_min[k]; gf.dim[k] = ctx->photon_grid_dim_f[k]; }
+			for (int k = 0; k < 3; ++k) { gf.mn[k] = ctx->photon_grid_min_f[k]; gf.dim[k] = ctx->photon_grid_dim_f[k]; }
 			gf.cell = ctx->photon_cell_f; gf.inv_cell = 1.0f / ctx->photon_cell_f;
-			hipLaunchKernelGGL(k_photon_gather_wave<true>, dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
+#ifdef RT_GATHER_FUSED
+			hipLaunchKernelGGL((k_photon_gather_wave<true, 0>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1);
+#else
+			const int chunk1 = std::max(1, chunk / RT_GATHER_P1_WAVES), unit1 = 8 * chunk1;
+			const int blocks1 = (std::min(npts, 64 * 1024) / RT_GATHER_P1_WAVES + unit1 - 1) / unit1 * unit1;
+			hipLaunchKernelGGL((k_photon_gather_wave<true, 1>), dim3(blocks1), dim3(64 * RT_GATHER_P1_WAVES), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
+			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1);
+			hipLaunchKernelGGL((k_photon_gather_wave<true, 2>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
+			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1);
+#endif
 		} else {
-			hipLaunchKernelGGL(k_photon_gather_wave<false>, dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
+			hipLaunchKernelGGL((k_photon_gather_wave<false, 0>), dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
 			                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1);
 		}
 		RT_HIP_CHECK(hipGetLastError());
 	}
@@ -1110,3 +1190,13 @@ int rt_photon_unpermute(rt_hip_ctx* ctx, float* d_out)
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }
+
+#ifdef RT_GATHER_PROBE
+extern "C" int rt_hip_debug_gather_probe(unsigned long long* out8, int reset)
+{
+	unsigned long long z[16] = {};
+	if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gather_probe), sizeof(z)) != hipSuccess) return -1;
+	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_gather_probe), z, sizeof(z)) != hipSuccess) return -1;
+	return 0;
+}
+#endif

@@ -187,6 +187,7 @@ struct rt_hip_ctx {
 	// the same photons in a second, finer grid (cell = radius / 8): what the wave-per-point gather reads
 	DevBuf d_photons_f, d_photon_sorted_f, d_cell_start_f;
 	float photon_cell_f = 1.0f;
+	float photon_grid_min_f[3];
 	int photon_grid_dim_f[3];
 
 	// multi-GPU (k_comm.hip)

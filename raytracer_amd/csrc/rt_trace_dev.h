@@ -81,8 +81,14 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 		const int EXIT = 0x7fffffff;
 		int cur = (sv.num_tris == 1) ? ~0 : 0;
 		int sp = 0;
+#ifdef RT_SHARE_OCCLUDER
+		int shares_left = RT_SHARE_OCCLUDER;
+#endif
 		while (cur != EXIT) {
 			bool pop;
+#ifdef RT_SHARE_OCCLUDER
+			bool hit_now = false;
+#endif
 			if (cur >= 0) {
 				const uint4* np = (const uint4*)(sv.qnodes + cur);
 				const uint4 w0 = np[0], w1 = np[1];
@@ -107,12 +113,33 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 				if (CENSUS) ++cnt_tris;
 				f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
 				if (ANY) {
+#ifdef RT_SHARE_OCCLUDER
+					hit_now = mt_any(O, D, v0, e1, e2, sv.tp);
+#else
 					if (mt_any(O, D, v0, e1, e2, sv.tp)) { found = true; break; }
+#endif
 				} else {
 					if (mt_closest(O, D, v0, e1, e2, __float_as_uint(a.w), sv.tp, best)) found = true;
 				}
 				pop = true;
 			}
+#ifdef RT_SHARE_OCCLUDER
+			if (ANY) {
+				// A lane that found an occluder offers it to the wave's other rays (neighbouring texels, same light):
+				// one more triangle test for everybody, and the rays it also blocks stop here.  Any accepted hit is a
+				// true hit, so the boolean result cannot change.
+				const uint64_t hm = __ballot(hit_now);
+				if (hm && shares_left > 0) {
+					--shares_left;
+					const int src = __ffsll((unsigned long long)hm) - 1;
+					const int tri = ~__builtin_amdgcn_readlane(cur, src);
+					const TriIsect* tp = sv.tris + tri;
+					const float4 a = tp->a, b = tp->b, c = tp->c;
+					if (!hit_now) hit_now = mt_any(O, D, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), sv.tp);
+				}
+				if (hit_now) { found = true; break; }
+			}
+#endif
 			if (pop) {
 				if (sp == 0) cur = EXIT;
 				else { --sp; cur = stack_pop(sv, stack, stride, sp); }

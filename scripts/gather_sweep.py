@@ -33,4 +33,11 @@ for spec in sys.argv[2:]:
     for _ in range(3):
         g.radiance_estimate_device(pos, nrm, pos.shape[0], 100, 1.0, out)
     st = g.stats()
-    print(json.dumps({"tuning": spec or "default", "photons": n, "points": int(pos.shape[0]), "gather_ms": round(st["gather_ms"] / 3, 3)}), flush=True)
+    rec = {"tuning": spec or "default", "photons": n, "points": int(pos.shape[0]), "gather_ms": round(st["gather_ms"] / 3, 3)}
+    if hasattr(rt.load_library(), "rt_hip_debug_gather_probe"):   # probe builds (-DRT_GATHER_PROBE): per gather
+        import ctypes
+        buf = (ctypes.c_ulonglong * 16)()
+        rt.load_library().rt_hip_debug_gather_probe(buf, 1)
+        names = ["calls", "calls_nonempty", "rounds", "elements", "long_runs", "long_elements", "short_runs", "-"]
+        rec["probe_per_gather"] = {k: v // 4 for k, v in zip(names, buf) if k != "-"}
+    print(json.dumps(rec), flush=True)
