@@ -311,8 +311,25 @@ __device__ unsigned long long g_gather_probe[16];
 #else
 #define RT_PROBE_ADD(i, v) do {} while (0)
 #endif
-template <typename V>
-__device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, uint32_t r0, uint32_t r1, V visit)
+// Inclusive scans across the 64 lanes on the DPP network (no LDS traffic): within rows of 16 by row_shr 1, 2, 4, 8, then
+// row 0's total into row 1 and row 2's into row 3 (row_bcast:15), then the lower half's total into the upper (row_bcast:31).
+#define RT_DPP_SCAN(v, OP)                                                                                      \
+	do {                                                                                                        \
+		v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x111, 0xf, 0xf, false));                  \
+		v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x112, 0xf, 0xf, false));                  \
+		v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x114, 0xf, 0xf, false));                  \
+		v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x118, 0xf, 0xf, false));                  \
+		v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x142, 0xa, 0xf, false));                  \
+		v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x143, 0xc, 0xf, false));                  \
+	} while (0)
+__device__ __forceinline__ uint32_t dpp_op_add(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t dpp_op_max(uint32_t a, uint32_t b) { return max(a, b); }
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) { RT_DPP_SCAN(v, dpp_op_add); return v; }
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) { RT_DPP_SCAN(v, dpp_op_max); return v; }
+
+// `mark`: 64 dwords of LDS owned by the calling wave.
+template <bool MARKS, typename V>
+__device__ __forceinline__ void wave_visit_runs(uint32_t* mark, const float4* __restrict__ pos, uint32_t r0, uint32_t r1, V visit)
 {
 	const int lane = lane_id();
 	uint32_t len = r1 > r0 ? r1 - r0 : 0u;
@@ -338,43 +355,79 @@ __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, 
 		}
 	}
 	if (len >= RT_GATHER_LONG) len = 0u;
-	uint32_t end = len;   // inclusive prefix sum over the lanes
-	for (int off = 1; off < 64; off <<= 1) {
-		const uint32_t y = __shfl_up(end, off);
-		if (lane >= off) end += y;
-	}
+	const uint32_t end = wave_scan_add_u32(len);   // inclusive prefix sum over the lanes
 	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
 	RT_PROBE_ADD(1, total > 0u);
 	RT_PROBE_ADD(2, (total + 255u) / 256u);
 	RT_PROBE_ADD(3, total);
 	RT_PROBE_ADD(6, __popcll(__ballot(len > 0u)));
 	const uint32_t base = r0 - (end - len);   // slot of flattened element e inside this lane's run = base + e
-	// Each lane takes FOUR consecutive elements of the concatenation per round: one binary search for the first, and the
-	// run of each next element is the same one or the next non-empty one (one shuffle to find out).
+	// Each lane takes FOUR consecutive elements of the concatenation per round.  Which run an element belongs to: every
+	// non-empty run that starts inside the round's 256 elements writes its lane number + 1 into a byte table at its start
+	// (starts are distinct), and an element's run is the maximum of the marks at or before it -- the lane's own four bytes,
+	// a max-scan across the lanes, and the last run of the rounds before.  (A 6-step binary search over the prefix sums by
+	// shuffles, plus a shuffle per further element, cost 4 x the instructions.)
 	const uint64_t nonempty = __ballot(len > 0u);
 	const uint32_t first_slot = nonempty ? (uint32_t)__builtin_amdgcn_readlane((int)r0, __ffsll((unsigned long long)nonempty) - 1) : 0u;
+	const uint32_t start = end - len;
+	uint32_t carry = 0u;   // mark of the last run that started before this round
+	if constexpr (!MARKS) {
+		// the older form, kept for the short sweeps of the selection, which measured faster with it: one binary search over
+		// the lanes' prefix sums per lane and round, then one shuffle per further element (same run, or the next non-empty one)
+		for (uint32_t e0 = 0; e0 < total; e0 += 256) {
+			float4 q[4];
+			uint32_t slot[4];
+			bool act[4];
+			const uint32_t e = e0 + 4u * lane;
+			int j = 0;   // the first lane whose prefix sum exceeds e (never an empty run)
+#pragma unroll
+			for (int step = 32; step >= 1; step >>= 1)
+				if (__shfl(end, min(j + step - 1, 63)) <= e) j += step;
+			j = min(j, 63);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t ek = e + k;
+				act[k] = ek < total;
+				if (k > 0) {
+					const uint32_t t = __shfl(end, j);
+					if (t <= ek) {
+						const uint64_t rest = j >= 63 ? 0ull : (nonempty >> (j + 1));
+						j = rest ? j + __ffsll((unsigned long long)rest) : 63;
+					}
+				}
+				slot[k] = __shfl(base, j) + ek;
+				q[k] = pos[act[k] ? slot[k] : first_slot];
+			}
+#pragma unroll
+			for (int k = 0; k < 4; ++k) visit(q[k], slot[k], act[k]);
+		}
+		return;
+	}
 	for (uint32_t e0 = 0; e0 < total; e0 += 256) {
 		float4 q[4];
 		uint32_t slot[4];
 		bool act[4];
 		const uint32_t e = e0 + 4u * lane;
-		int j = 0;   // the first lane whose prefix sum exceeds e (never an empty run)
-#pragma unroll
-		for (int step = 32; step >= 1; step >>= 1)
-			if (__shfl(end, min(j + step - 1, 63)) <= e) j += step;
-		j = min(j, 63);
+		mark[lane] = 0u;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		if (len > 0u && start - e0 < 256u) ((uint8_t*)mark)[start - e0] = (uint8_t)(lane + 1);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		const uint32_t w = mark[lane];
+		uint32_t own[4];
+		own[0] = w & 0xffu;
+		own[1] = max(own[0], (w >> 8) & 0xffu);
+		own[2] = max(own[1], (w >> 16) & 0xffu);
+		own[3] = max(own[2], w >> 24);
+		const uint32_t inc = wave_scan_max_u32(own[3]);
+		// the lanes before this one: inc shifted up by a lane (wave_shr:1), the carry into lane 0
+		const uint32_t before = max(carry, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x138, 0xf, 0xf, false));
+		carry = max(carry, (uint32_t)__builtin_amdgcn_readlane((int)inc, 63));
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t ek = e + k;
 			act[k] = ek < total;
-			if (k > 0) {
-				const uint32_t t = __shfl(end, j);
-				if (t <= ek) {
-					const uint64_t rest = j >= 63 ? 0ull : (nonempty >> (j + 1));
-					j = rest ? j + __ffsll((unsigned long long)rest) : 63;
-				}
-			}
-			slot[k] = __shfl(base, j) + ek;
+			const uint32_t o = max(own[k], before);   // >= 1 for every element below `total`
+			slot[k] = __shfl(base, (int)((o - 1u) & 63u)) + ek;
 			// unconditional (see above): the four loads are in flight together; padding lanes read the run's first slot
 			q[k] = pos[act[k] ? slot[k] : first_slot];
 		}
@@ -386,8 +439,11 @@ __device__ __forceinline__ void wave_visit_runs(const float4* __restrict__ pos, 
 // The walk of for_each_neighbour with a whole wave on one point (P and rho are wave-uniform): the grid rows of the cube
 // are dealt to the lanes, 64 at a time, each lane looks up its row's run, and the wave visits the 64 runs together.
 // f(slot, l2, active) runs in uniform control flow, `active` false in the padding.
-template <typename F>
-__device__ __forceinline__ void for_each_neighbour_wave(const GridDesc& gd, const uint32_t* __restrict__ cell_start,
+#ifndef RT_GATHER_MARKS_SEL   // probe builds: 1 = the selection's sweeps use the byte table too
+#define RT_GATHER_MARKS_SEL 0
+#endif
+template <bool MARKS = (RT_GATHER_MARKS_SEL != 0), typename F>
+__device__ __forceinline__ void for_each_neighbour_wave(uint32_t* mark, const GridDesc& gd, const uint32_t* __restrict__ cell_start,
                                                         const float4* __restrict__ pos, f3 P, float rho, F f)
 {
 	rho = rho * 1.0001f + 1e-30f;
@@ -409,7 +465,7 @@ __device__ __forceinline__ void for_each_neighbour_wave(const GridDesc& gd, cons
 				s0 = cell_start[rb + x0]; s1 = cell_start[rb + x1 + 1];
 			}
 		}
-		wave_visit_runs(pos, s0, s1, [&](const float4 q, uint32_t slot, bool act) {
+		wave_visit_runs<MARKS>(mark, pos, s0, s1, [&](const float4 q, uint32_t slot, bool act) {
 			const f3 d = mk3(q.x, q.y, q.z) - P;
 			f(slot, dot3(d, d), act);
 		});
@@ -440,7 +496,7 @@ __device__ __forceinline__ float wave_max_f(float v)
 // corner is farther than the best shell candidate, e.g. an empty shell) is that run read too, in a second sweep.
 // Rows are dealt to the lanes for the table work, the wave then reads the 64 rows' shell runs together.
 template <bool SECOND>
-__device__ __forceinline__ void wave_shell_sweep(const GridDesc& gd, const uint32_t* __restrict__ cs, const float4* __restrict__ pos,
+__device__ __forceinline__ void wave_shell_sweep(uint32_t* mark, const GridDesc& gd, const uint32_t* __restrict__ cs, const float4* __restrict__ pos,
                                                  f3 P, float radius, float r2, float mx_in, int& nc_l, float& mx_l, float& bound_l)
 {
 	const float rho = radius * 1.0001f + 1e-30f;
@@ -506,8 +562,8 @@ __device__ __forceinline__ void wave_shell_sweep(const GridDesc& gd, const uint3
 			mx_l = __uint_as_float(max(__float_as_uint(mx_l), in ? __float_as_uint(l2) : 0u));
 		};
 #ifndef RT_GATHER_NOVISIT   // probe builds: the row tables alone
-		wave_visit_runs(pos, a0, a1, visit);
-		if (__ballot(b1 > b0)) wave_visit_runs(pos, b0, b1, visit);
+		wave_visit_runs<true>(mark, pos, a0, a1, visit);
+		if (__ballot(b1 > b0)) wave_visit_runs<true>(mark, pos, b0, b1, visit);
 #else
 		(void)visit;
 #endif
@@ -527,6 +583,7 @@ constexpr int GBLOCK = 128;
 constexpr int SEL_BINS = 64;
 constexpr int SEL_LEVELS = 4;
 constexpr int SEL_LIST = 64;
+constexpr int SEL_BELOW = 256;  // wave kernel: selected photons queued for the sum
 
 struct SelLevel {
 	float lo, scale;  // bin(l2) = clamp(int((l2 - lo) * scale), 0, 63)
@@ -721,9 +778,13 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                            float2* __restrict__ p1)
 {
 	__shared__ uint32_t s_hist[SEL_BINS];
-	__shared__ uint32_t s_list[SEL_LIST];
+	__shared__ uint32_t s_list[SEL_LIST], s_lslot[SEL_LIST];
+	__shared__ float s_bl2[SEL_BELOW];        // photons below the count-th's bin: squared distance and sorted slot
+	__shared__ uint32_t s_bslot[SEL_BELOW];
 	__shared__ uint32_t s_m, s_tau;
 	__shared__ int s_take;
+	__shared__ uint32_t s_mark[PHASE == 1 ? RT_GATHER_P1_WAVES : 1][64];   // wave_visit_runs' byte table, one per wave
+	uint32_t* mark = s_mark[PHASE == 1 ? (threadIdx.x >> 6) : 0];
 	static_assert(SEL_BINS == 64, "one histogram bin per lane");
 	const int lane = lane_id();
 	const int nheavy = *heavy_count;
@@ -757,16 +818,16 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 			int nc_l = 0;
 			float mx_l = 0.0f, bound_l = 0.0f;
 			if (SHELL) {
-				wave_shell_sweep<false>(gd, cell_start, pos, P, radius, r2, 0.0f, nc_l, mx_l, bound_l);
+				wave_shell_sweep<false>(mark, gd, cell_start, pos, P, radius, r2, 0.0f, nc_l, mx_l, bound_l);
 			} else {
-				for_each_neighbour_wave(gd, cell_start, pos, P, radius, [&](uint32_t, float l2, bool act) {
+				for_each_neighbour_wave(mark, gd, cell_start, pos, P, radius, [&](uint32_t, float l2, bool act) {
 					if (act && l2 < r2) { ++nc_l; mx_l = fmaxf(mx_l, l2); }
 				});
 			}
 			nc = wave_sum_i(nc_l);
 			max_dist2 = wave_max_f(mx_l);
 			if (SHELL && wave_max_f(bound_l) > max_dist2) {   // rare: an interior run could hold the farthest candidate
-				wave_shell_sweep<true>(gd, cell_start, pos, P, radius, r2, max_dist2, nc_l, mx_l, bound_l);
+				wave_shell_sweep<true>(mark, gd, cell_start, pos, P, radius, r2, max_dist2, nc_l, mx_l, bound_l);
 				max_dist2 = wave_max_f(mx_l);
 			}
 			if constexpr (PHASE == 1) {
@@ -785,6 +846,8 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 		uint32_t tau = 0xFFFFFFFFu;
 		int take_equal = 0x7fffffff;
 		float rho_sel = radius;
+		f3 result = mk3(0, 0, 0);
+		bool summed = false;
 		if (nc > count) {
 			// level-0 histogram.  Photons lie on surfaces, so their number grows like l2: the count-th is
 			// expected near r2 * count / nc.  The histogram first covers [0, 4x that) and reads only the
@@ -797,13 +860,12 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 				s_hist[lane] = 0u;
 				__syncthreads();
 				const float rho0 = top < r2 ? fminf(radius, rt_sqrtf(top) * 1.001f) : radius;
-				for_each_neighbour_wave(gd, cell_start, pos, P, rho0, [&](uint32_t, float l2, bool act) {
+				for_each_neighbour_wave(mark, gd, cell_start, pos, P, rho0, [&](uint32_t, float l2, bool act) {
 					if (act && l2 < r2) atomicAdd(&s_hist[sel_bin(l2, lv[0].lo, lv[0].scale)], 1u);
 				});
 				__syncthreads();
 				if (!(top < r2)) break;
-				int below = 0;
-				for (int b = 0; b < SEL_BINS - 1; ++b) below += (int)s_hist[b];
+				const int below = wave_sum_i(lane < SEL_BINS - 1 ? (int)s_hist[lane] : 0);
 				if (below >= count) break;
 				top = r2;
 			}
@@ -811,14 +873,17 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 			int pop = nc;
 			float hi_edge = r2;
 			for (;;) {
-				int b = 0, cum = 0;
-				for (; b < SEL_BINS - 1; ++b) {
-					int hh = (int)s_hist[b];
-					if (cum + hh >= need) break;
-					cum += hh;
+				// the bin that holds the need-th candidate: one bin per lane, prefix sums across the lanes
+				const int hh = (int)s_hist[lane];
+				int pre = hh;
+				for (int off = 1; off < 64; off <<= 1) {
+					const int y = __shfl_up(pre, off);
+					if (lane >= off) pre += y;
 				}
-				need -= cum;
-				pop = (int)s_hist[b];
+				const uint64_t ge = __ballot(pre >= need) & ~(1ull << (SEL_BINS - 1));
+				const int b = ge ? __ffsll((unsigned long long)ge) - 1 : SEL_BINS - 1;
+				need -= __builtin_amdgcn_readlane(pre, b) - __builtin_amdgcn_readlane(hh, b);
+				pop = __builtin_amdgcn_readlane(hh, b);
 				const float width = 1.0f / lv[nlv].scale;
 				const float lo_edge = lv[nlv].lo + (float)b * width;
 				if (b < SEL_BINS - 1) hi_edge = fminf(hi_edge, lo_edge + width * 1.001f + fabsf(lo_edge) * 4e-6f);
@@ -831,25 +896,61 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 				s_hist[lane] = 0u;
 				__syncthreads();
 				const int upto = nlv;
-				for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
+				for_each_neighbour_wave(mark, gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
 					if (act && in_levels(l2, upto)) atomicAdd(&s_hist[sel_bin(l2, lv[upto].lo, lv[upto].scale)], 1u);
 				});
 				__syncthreads();
 			}
 			if (pop <= SEL_LIST) {
+				// One sweep for the rest: a photon in an earlier bin than the count-th's (at the first level where they
+				// differ) is certainly selected and is summed (:178-197) at once; the photons of the count-th's own bin
+				// go to a list in LDS with their slots, are ranked there, and the selected ones are summed from the list.
 				const int upto = nlv;
 				if (lane == 0) { s_m = 0u; s_tau = 0xFFFFFFFFu; s_take = 0x7fffffff; }
 				__syncthreads();
-				for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
-					if (act && in_levels(l2, upto)) {
-						uint32_t slot = atomicAdd(&s_m, 1u);
-						if (slot < (uint32_t)SEL_LIST) s_list[slot] = __float_as_uint(l2);
+				const float denom2 = 2.0f * max_dist2;
+				auto contribution = [&](uint32_t s, float l2) {
+					float w = 1.0f - powf(gc.e, -gc.beta * (l2 / denom2));
+					w *= gc.gauss_denom;
+					w = gc.alpha * (1.0f - w);
+					const float4 a = payload[2 * (size_t)s], c = payload[2 * (size_t)s + 1];
+					const f3 energy = mk3(a.x, a.y, a.z), dir = mk3(a.w, c.x, c.y);
+					float brdf = dot3(N, neg3(dir));
+					brdf = fminf(fmaxf(brdf, 0.0f), 1.0f);
+					return (energy * brdf) * w;
+				};
+				int m_in = 0, m_below = 0;   // wave-uniform list lengths; slots by ballot rank, so both lists are in walk order
+				for_each_neighbour_wave(mark, gd, cell_start, pos, P, rho_sel, [&](uint32_t s, float l2, bool act) {
+					int cls = 2;   // -1 below the count-th's bin, 0 in it, 1 above, 2 not a candidate
+					if (act && l2 < r2) {
+						cls = 0;
+						for (int k = 0; k < SEL_LEVELS; ++k)
+							if (k < upto && cls == 0) {
+								const int bk = sel_bin(l2, lv[k].lo, lv[k].scale);
+								cls = bk < lv[k].bin ? -1 : bk > lv[k].bin ? 1 : 0;
+							}
 					}
+					const uint64_t im = __ballot(cls == 0), bm = __ballot(cls == -1);
+					if (cls == 0) {
+						const int at = m_in + (int)__popcll(im & lanemask_lt());
+						if (at < SEL_LIST) { s_list[at] = __float_as_uint(l2); s_lslot[at] = s; }
+					}
+					if (cls == -1) {
+						// summed after the sweep, 64 at a time (here the weight's powf would run for a few lanes per call);
+						// what does not fit the list (count > SEL_BELOW) is summed on the spot
+						const int at = m_below + (int)__popcll(bm & lanemask_lt());
+						if (at < SEL_BELOW) { s_bl2[at] = l2; s_bslot[at] = s; }
+						else result = result + contribution(s, l2);
+					}
+					m_in += (int)__popcll(im);
+					m_below += (int)__popcll(bm);
 				});
 				__syncthreads();
-				const int m = (int)min(s_m, (uint32_t)SEL_LIST);
+				for (int i = lane; i < min(m_below, SEL_BELOW); i += 64) result = result + contribution(s_bslot[i], s_bl2[i]);
+				const int m = min(m_in, SEL_LIST);
+				uint32_t v = 0xFFFFFFFFu;
 				if (lane < m) {
-					const uint32_t v = s_list[lane];
+					v = s_list[lane];
 					int lt = 0, le = 0;
 					for (int c = 0; c < m; ++c) {
 						const uint32_t x = s_list[c];
@@ -860,13 +961,21 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 				}
 				__syncthreads();
 				tau = s_tau; take_equal = s_take;
+				{   // of the photons AT tau the first take_equal of the list are taken
+					const bool eq = lane < m && v == tau;
+					const uint64_t em = __ballot(eq);
+					const bool sel = lane < m && (v < tau || (eq && (int)__popcll(em & lanemask_lt()) < take_equal));
+					if (sel) result = result + contribution(s_lslot[lane], __uint_as_float(v));
+				}
+				result.x = wave_sum_f(result.x); result.y = wave_sum_f(result.y); result.z = wave_sum_f(result.z);
+				summed = true;
 			} else {
 				const int upto = nlv;
 				uint32_t lo = 0u, hi = __float_as_uint(r2);
 				while (lo < hi) {
 					uint32_t mid = lo + ((hi - lo) >> 1);
 					int c = 0;
-					for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
+					for_each_neighbour_wave(mark, gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
 						if (act && in_levels(l2, upto) && __float_as_uint(l2) <= mid) ++c;
 					});
 					c = wave_sum_i(c);
@@ -874,7 +983,7 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 				}
 				tau = lo;
 				int less = 0;
-				for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
+				for_each_neighbour_wave(mark, gd, cell_start, pos, P, rho_sel, [&](uint32_t, float l2, bool act) {
 					if (act && in_levels(l2, upto) && __float_as_uint(l2) < tau) ++less;
 				});
 				take_equal = need - wave_sum_i(less);
@@ -884,12 +993,11 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 		if (lane == 0) st3(rgb + 3 * (size_t)i, mk3((float)nc, max_dist2, __uint_as_float(tau)));
 		continue;
 #endif
-		// pass 3
-		f3 result = mk3(0, 0, 0);
-		if (nc > 0) {
+		// pass 3 (unless the sweep above has summed already)
+		if (nc > 0 && !summed) {
 			const float denom2 = 2.0f * max_dist2;
 			int taken = 0;  // photons at tau already taken, in walk order (wave-uniform)
-			for_each_neighbour_wave(gd, cell_start, pos, P, rho_sel, [&](uint32_t s, float l2, bool act) {
+			for_each_neighbour_wave(mark, gd, cell_start, pos, P, rho_sel, [&](uint32_t s, float l2, bool act) {
 				const uint32_t b = __float_as_uint(l2);
 				const bool inr = act && l2 < r2;
 				const bool eq = inr && b == tau;
@@ -922,6 +1030,8 @@ __global__ __launch_bounds__(64) void k_photon_lookup(GridDesc gd, const uint32_
                                                       const float* __restrict__ qpos, int npts, float radius,
                                                       float* __restrict__ rgb)
 {
+	__shared__ uint32_t s_mark1[64];
+	uint32_t* mark = s_mark1;
 	const float r2 = radius * radius;
 	for (int i = blockIdx.x; i < npts; i += gridDim.x) {
 		f3 P;
@@ -929,7 +1039,7 @@ __global__ __launch_bounds__(64) void k_photon_lookup(GridDesc gd, const uint32_
 		P.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 1])));
 		P.z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 2])));
 		f3 sum = mk3(0, 0, 0);
-		for_each_neighbour_wave(gd, cell_start, pos, P, radius, [&](uint32_t s, float l2, bool act) {
+		for_each_neighbour_wave(mark, gd, cell_start, pos, P, radius, [&](uint32_t s, float l2, bool act) {
 			if (act && l2 < r2) {
 				const float4 a = payload[2 * (size_t)s];
 				sum = sum + mk3(a.x, a.y, a.z);
@@ -1147,7 +1257,7 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1);
 #else
 			const int chunk1 = std::max(1, chunk / RT_GATHER_P1_WAVES), unit1 = 8 * chunk1;
-			const int blocks1 = (std::min(npts, 64 * 1024) / RT_GATHER_P1_WAVES + unit1 - 1) / unit1 * unit1;
+			const int blocks1 = ((std::min(npts, 64 * 1024) + RT_GATHER_P1_WAVES - 1) / RT_GATHER_P1_WAVES + unit1 - 1) / unit1 * unit1;
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 1>), dim3(blocks1), dim3(64 * RT_GATHER_P1_WAVES), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
 			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1);

@@ -33,7 +33,9 @@ for spec in sys.argv[2:]:
     for _ in range(3):
         g.radiance_estimate_device(pos, nrm, pos.shape[0], 100, 1.0, out)
     st = g.stats()
-    rec = {"tuning": spec or "default", "photons": n, "points": int(pos.shape[0]), "gather_ms": round(st["gather_ms"] / 3, 3)}
+    fin = torch.isfinite(out)
+    rec = {"tuning": spec or "default", "photons": n, "points": int(pos.shape[0]), "gather_ms": round(st["gather_ms"] / 3, 3),
+           "checksum": [float(out[fin].double().sum()), int((~fin).sum())]}
     if hasattr(rt.load_library(), "rt_hip_debug_gather_probe"):   # probe builds (-DRT_GATHER_PROBE): per gather
         import ctypes
         buf = (ctypes.c_ulonglong * 16)()
