@@ -10,8 +10,9 @@ import csv, sys
 out = []
 for r in csv.DictReader(open("gpurun_out/gk_prof/gk_kernel_stats.csv")):
     n = r["Name"]
-    if "photon_gather" in n:
-        tag = "wave<1>" if "wave<true, 1>" in n else "wave<2>" if "wave<true, 2>" in n else "wave<0>" if "gather_wave" in n else "lane"
+    if "photon_gather" in n or "photon_classify" in n:
+        tag = ("classify" if "classify" in n else "wave<1>" if "wave<true, 1>" in n else "wave<2>" if "wave<true, 2>" in n
+               else "wave<0>" if "gather_wave" in n else "lane")
         out.append("%s %.3f ms" % (tag, float(r["AverageNs"]) / 1e6))
 import os
 print("%-40s %s" % ((os.environ.get("LABEL", "") + " " + (sys.argv[1] or "default")).strip(), "  ".join(sorted(out))))
