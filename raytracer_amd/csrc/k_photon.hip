@@ -775,7 +775,8 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                            const int* __restrict__ heavy_queue,
                                                            const int* __restrict__ heavy_count, int count, float radius,
                                                            GatherConst gc, float* __restrict__ rgb, int xcd_chunk,
-                                                           float2* __restrict__ p1)
+                                                           float2* __restrict__ p1, const int* __restrict__ sub_queue,
+                                                           const int* __restrict__ sub_count)
 {
 	__shared__ uint32_t s_hist[SEL_BINS];
 	__shared__ uint32_t s_list[SEL_LIST], s_lslot[SEL_LIST];
@@ -787,7 +788,8 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 	uint32_t* mark = s_mark[PHASE == 1 ? (threadIdx.x >> 6) : 0];
 	static_assert(SEL_BINS == 64, "one histogram bin per lane");
 	const int lane = lane_id();
-	const int nheavy = *heavy_count;
+	// sub_queue (PHASE 2 only): positions in the heavy queue that k_photon_select_common left to this kernel
+	const int nheavy = sub_queue ? *sub_count : *heavy_count;
 	const float r2 = radius * radius;
 	// XCD-aware order (rt_trace_dev.h: xcd_block_index): XCD x takes `xcd_chunk` consecutive queue entries of every
 	// group of 8 * xcd_chunk.  Queue order is screen order, neighbouring points read nearly the same photons, and the
@@ -795,7 +797,8 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 	// PHASE 1 runs several waves per workgroup, each on a point of its own: neighbours in the queue, hence in the frame,
 	// read the same photons at the same time through one L1
 	const int nw = PHASE == 1 ? RT_GATHER_P1_WAVES : 1, wv = PHASE == 1 ? (int)(threadIdx.x >> 6) : 0;
-	for (int h = (int)xcd_block_index(xcd_chunk) * nw + wv; h < nheavy; h += gridDim.x * nw) {
+	for (int hq = (int)xcd_block_index(xcd_chunk) * nw + wv; hq < nheavy; hq += gridDim.x * nw) {
+		const int h = sub_queue ? __builtin_amdgcn_readfirstlane(sub_queue[hq]) : hq;
 		const int i = __builtin_amdgcn_readfirstlane(heavy_queue[h]);
 		f3 P, N;
 		P.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 0])));
@@ -852,7 +855,7 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 			// level-0 histogram.  Photons lie on surfaces, so their number grows like l2: the count-th is
 			// expected near r2 * count / nc.  The histogram first covers [0, 4x that) and reads only the
 			// cells within its upper edge; if the count-th is not below the edge after all (its bin would
-			// be the top one, whose population the short walk does not know), the full range is taken.
+			// be the top one, whose population the short walk does not know), the range is widened fourfold.
 			float top = fminf(r2, r2 * (4.0f * (float)count / (float)nc));
 			for (;;) {
 				lv[0].lo = 0.0f; lv[0].scale = (float)SEL_BINS / top; lv[0].bin = 0;
@@ -867,7 +870,7 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 				if (!(top < r2)) break;
 				const int below = wave_sum_i(lane < SEL_BINS - 1 ? (int)s_hist[lane] : 0);
 				if (below >= count) break;
-				top = r2;
+				top = fminf(r2, top * 4.0f);
 			}
 			int need = count;
 			int pop = nc;
@@ -1020,6 +1023,143 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 		}
 		result = div3(result, gc.two_pi * max_dist2);
 		if (lane == 0) st3(rgb + 3 * (size_t)i, result);
+	}
+}
+
+// The selection and the sum for the USUAL heavy point, after pass 1 (PHASE 1 above): more photons within the radius than
+// wanted, the count-th distance inside the first histogram's range, at most SEL_LIST photons in its bin.  Two sweeps:
+// the level-0 histogram over the cells within the radius expected to hold 4 x count photons, then the sweep that sums
+// what lies below the count-th's bin and lists the bin itself (ranked in LDS, the selected ones summed from the list).
+// Every other case (fewer photons than wanted, an estimate that fell short, a crowded bin) is queued for PHASE 2 of
+// k_photon_gather_wave, which handles all of them.  Same bins, same tie rule, same results; the point of a kernel of its
+// own is its size: the general kernel carries eight inlined sweeps, holds 220 VGPRs and spills at 4 waves per SIMD.
+#ifndef RT_GATHER_WAVES2C
+#define RT_GATHER_WAVES2C 6
+#endif
+#ifndef RT_GATHER_MARKS_COMMON   // probe builds: 0 = the binary-search flattening in this kernel
+#define RT_GATHER_MARKS_COMMON 1
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES2C, RT_GATHER_WAVES2C)))
+void k_photon_select_common(GridDesc gd, const uint32_t* __restrict__ cell_start, const float4* __restrict__ pos,
+                            const float4* __restrict__ payload, const float* __restrict__ qpos, const float* __restrict__ qnrm,
+                            const int* __restrict__ heavy_queue, const int* __restrict__ heavy_count, int count, float radius,
+                            GatherConst gc, float* __restrict__ rgb, int xcd_chunk, const float2* __restrict__ p1,
+                            int* __restrict__ sub_queue, int* __restrict__ sub_count)
+{
+	__shared__ uint32_t s_hist[SEL_BINS];
+	__shared__ uint32_t s_list[SEL_LIST], s_lslot[SEL_LIST];
+	__shared__ float s_bl2[SEL_BELOW];
+	__shared__ uint32_t s_bslot[SEL_BELOW];
+	__shared__ uint32_t s_tau;
+	__shared__ int s_take;
+	__shared__ uint32_t s_mark[64];
+	uint32_t* mark = s_mark;
+	const int lane = lane_id();
+	const int nheavy = *heavy_count;
+	const float r2 = radius * radius;
+	for (int h = (int)xcd_block_index(xcd_chunk); h < nheavy; h += gridDim.x) {
+		const int i = __builtin_amdgcn_readfirstlane(heavy_queue[h]);
+		f3 P, N;
+		P.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 0])));
+		P.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 1])));
+		P.z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)i + 2])));
+		N = ld3(qnrm + 3 * (size_t)i);
+		const float2 r = p1[h];
+		const int nc = __builtin_amdgcn_readfirstlane(__float_as_int(r.x));
+		const float max_dist2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r.y)));
+		bool common = nc > count;
+		if (common) {
+			// level-0 histogram over [0, top): the count-th is expected near r2 * count / nc (photons lie on surfaces)
+			// If the count-th is not below the range after all (the top bin also counts what lies beyond it), the range
+			// is widened fourfold and the histogram redone: the density around a point is not uniform.
+			float top = fminf(r2, r2 * (4.0f * (float)count / (float)nc));
+			float scale;
+			int hh;
+			for (;;) {
+				scale = (float)SEL_BINS / top;
+				__syncthreads();   // earlier readers are done with the shared state
+				s_hist[lane] = 0u;
+				if (lane == 0) { s_tau = 0xFFFFFFFFu; s_take = 0x7fffffff; }
+				__syncthreads();
+				const float rho0 = top < r2 ? fminf(radius, rt_sqrtf(top) * 1.001f) : radius;
+				for_each_neighbour_wave<(RT_GATHER_MARKS_COMMON != 0)>(mark, gd, cell_start, pos, P, rho0, [&](uint32_t, float l2, bool act) {
+					if (act && l2 < r2) atomicAdd(&s_hist[sel_bin(l2, 0.0f, scale)], 1u);
+				});
+				__syncthreads();
+				hh = (int)s_hist[lane];
+				if (!(top < r2) || wave_sum_i(lane < SEL_BINS - 1 ? hh : 0) >= count) break;
+				top = fminf(r2, top * 4.0f);
+			}
+			{
+				int pre = (int)wave_scan_add_u32((uint32_t)hh);
+				const uint64_t ge = __ballot(pre >= count) & ~(1ull << (SEL_BINS - 1));
+				const int b = ge ? __ffsll((unsigned long long)ge) - 1 : SEL_BINS - 1;
+				const int need = count - (__builtin_amdgcn_readlane(pre, b) - __builtin_amdgcn_readlane(hh, b));
+				const int pop = __builtin_amdgcn_readlane(hh, b);
+				if (pop > SEL_LIST) common = false;
+				if (common) {
+					const float width = 1.0f / scale;
+					const float lo_edge = (float)b * width;
+					float hi_edge = r2;
+					if (b < SEL_BINS - 1) hi_edge = fminf(hi_edge, lo_edge + width * 1.001f + fabsf(lo_edge) * 4e-6f);
+					const float rho_sel = fminf(radius, rt_sqrtf(hi_edge) * 1.001f);
+					const float denom2 = 2.0f * max_dist2;
+					auto contribution = [&](uint32_t s, float l2) {
+						float w = 1.0f - powf(gc.e, -gc.beta * (l2 / denom2));
+						w *= gc.gauss_denom;
+						w = gc.alpha * (1.0f - w);
+						const float4 a = payload[2 * (size_t)s], c = payload[2 * (size_t)s + 1];
+						const f3 energy = mk3(a.x, a.y, a.z), dir = mk3(a.w, c.x, c.y);
+						float brdf = dot3(N, neg3(dir));
+						brdf = fminf(fmaxf(brdf, 0.0f), 1.0f);
+						return (energy * brdf) * w;
+					};
+					f3 result = mk3(0, 0, 0);
+					int m_in = 0, m_below = 0;   // wave-uniform list lengths; slots by ballot rank: both lists in walk order
+					for_each_neighbour_wave<(RT_GATHER_MARKS_COMMON != 0)>(mark, gd, cell_start, pos, P, rho_sel, [&](uint32_t s, float l2, bool act) {
+						const bool cand = act && l2 < r2;
+						const int bk = sel_bin(l2, 0.0f, scale);
+						const bool in = cand && bk == b, below = cand && bk < b;
+						const uint64_t im = __ballot(in), bm = __ballot(below);
+						if (in) {
+							const int at = m_in + (int)__popcll(im & lanemask_lt());
+							if (at < SEL_LIST) { s_list[at] = __float_as_uint(l2); s_lslot[at] = s; }
+						}
+						if (below) {
+							const int at = m_below + (int)__popcll(bm & lanemask_lt());
+							if (at < SEL_BELOW) { s_bl2[at] = l2; s_bslot[at] = s; }
+							else result = result + contribution(s, l2);
+						}
+						m_in += (int)__popcll(im);
+						m_below += (int)__popcll(bm);
+					});
+					__syncthreads();
+					for (int k = lane; k < min(m_below, SEL_BELOW); k += 64) result = result + contribution(s_bslot[k], s_bl2[k]);
+					const int m = min(m_in, SEL_LIST);
+					uint32_t v = 0xFFFFFFFFu;
+					if (lane < m) {
+						v = s_list[lane];
+						int lt = 0, le = 0;
+						for (int c = 0; c < m; ++c) {
+							const uint32_t x = s_list[c];
+							lt += x < v; le += x <= v;
+						}
+						if (lt < need && need <= le) { s_tau = v; s_take = need - lt; }
+					}
+					__syncthreads();
+					const uint32_t tau = s_tau;
+					const int take_equal = s_take;
+					const bool eq = lane < m && v == tau;
+					const uint64_t em = __ballot(eq);
+					const bool sel = lane < m && (v < tau || (eq && (int)__popcll(em & lanemask_lt()) < take_equal));
+					if (sel) result = result + contribution(s_lslot[lane], __uint_as_float(v));
+					result.x = wave_sum_f(result.x); result.y = wave_sum_f(result.y); result.z = wave_sum_f(result.z);
+					result = div3(result, gc.two_pi * max_dist2);
+					if (lane == 0) st3(rgb + 3 * (size_t)i, result);
+				}
+			}
+		}
+		if (!common && lane == 0) sub_queue[atomicAdd(sub_count, 1)] = h;
 	}
 }
 
@@ -1225,11 +1365,13 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	// on the device).  tuning.gather_heavy is the threshold (0: every point with a photon nearby takes
 	// the wave kernel; a huge value: none does) -- the parity tests run both extremes.
 	const uint32_t heavy = ctx->tuning.gather_heavy;
-	RT_CHECK(ctx->d_heavy.reserve(((size_t)npts + 16) * sizeof(int) + ((size_t)npts + 1) * sizeof(float2)));
+	RT_CHECK(ctx->d_heavy.reserve(((size_t)2 * npts + 16) * sizeof(int) + ((size_t)npts + 1) * sizeof(float2)));
 	int* heavy_count = ctx->d_heavy.as<int>();
+	int* sub_count = heavy_count + 1;              // heavy-queue positions left to the general selection kernel
 	int* heavy_queue = heavy_count + 16;
-	float2* pass1 = (float2*)(heavy_queue + npts + (npts & 1));   // (count, max_dist2) per queue entry, between the wave kernel's two launches
-	RT_HIP_CHECK(hipMemsetAsync(heavy_count, 0, sizeof(int), ctx->stream));
+	float2* pass1 = (float2*)(heavy_queue + npts + (npts & 1));   // (count, max_dist2) per queue entry, between the wave kernels' launches
+	int* sub_queue = (int*)(pass1 + npts + 1);
+	RT_HIP_CHECK(hipMemsetAsync(heavy_count, 0, 2 * sizeof(int), ctx->stream));
 	ctx->stats.gather_points += npts;
 	if (unsigned long long* cen = ctx->num_photons > 0 ? rt_census_ptr(ctx, 2) : nullptr) {
 		hipLaunchKernelGGL(k_photon_census, dim3(nblocks(npts, 256)), dim3(256), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
@@ -1254,21 +1396,31 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 #ifdef RT_GATHER_FUSED
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 0>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr);
 #else
 			const int chunk1 = std::max(1, chunk / RT_GATHER_P1_WAVES), unit1 = 8 * chunk1;
 			const int blocks1 = ((std::min(npts, 64 * 1024) + RT_GATHER_P1_WAVES - 1) / RT_GATHER_P1_WAVES + unit1 - 1) / unit1 * unit1;
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 1>), dim3(blocks1), dim3(64 * RT_GATHER_P1_WAVES), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1, (const int*)nullptr, (const int*)nullptr);
+#ifdef RT_GATHER_NO_COMMON   // probe builds: every heavy point through the general kernel
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 2>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr);
+#else
+			// the usual heavy point in the lean kernel; what it declines, in the general one
+			hipLaunchKernelGGL(k_photon_select_common, dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
+			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), d_pos, d_nrm, heavy_queue, heavy_count, count,
+			                   radius, gc, d_rgb, chunk, pass1, sub_queue, sub_count);
+			hipLaunchKernelGGL((k_photon_gather_wave<true, 2>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
+			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)sub_queue, (const int*)sub_count);
+#endif
 #endif
 		} else {
 			hipLaunchKernelGGL((k_photon_gather_wave<false, 0>), dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
 			                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr);
 		}
 		RT_HIP_CHECK(hipGetLastError());
 	}
