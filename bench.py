@@ -430,7 +430,7 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
         roof = {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
                 "traffic": counters.get("traffic_bytes_per_launch") if counters else None,
-                "kernel": "k_photon_gather + k_photon_gather_wave (radiance_estimate: one lane per point, one wave per point with > 1024 photons in its cube)",
+                "kernel": "k_photon_gather + k_photon_gather_wave (radiance_estimate: one lane per point, one wave per point with more than tuning.gather_heavy photons in its cube)",
                 "avg_launch_ms": round(avg_ms, 4), "share_of_frame_gpu_time": share(gat_ms),
                 "points_per_launch": round(points, 1), "photon_visits_per_launch": round(visits, 1),
                 "photon_visits_per_point": round(visits / max(points, 1), 1),

@@ -143,7 +143,7 @@ typedef struct rt_hip_tuning {
 	int auto_accel;           /* RT_HIP_ACCEL_PLOC  RT_HIP_AUTO_PLOC=0 -> LBVH: what RT_HIP_ACCEL_AUTO builds from 512 triangles on */
 	int ploc_radius;          /* 8    RT_HIP_PLOC_RADIUS: PLOC nearest-neighbour search radius (1..64) */
 	int frame_sync;           /* 0    RT_HIP_FRAME_SYNC: 1 = frames are rendered level by level with counts read back */
-	uint32_t gather_heavy;    /* 1024 RT_HIP_GATHER_HEAVY: a shading point with more photons in its cube takes the wave-per-point gather */
+	uint32_t gather_heavy;    /* 32 RT_HIP_GATHER_HEAVY: a shading point with more photons in its cube takes the wave-per-point gather */
 	int extra_lds_bytes;      /* 0    RT_HIP_EXTRA_LDS: extra LDS per trace workgroup (occupancy experiments) */
 	int max_bvh_depth;        /* 95   deepest BVH the traversal stack takes (<= 95); a deeper tree is not used: brute force serves the scene */
 	float refit_max_growth;   /* 2.0  RT_HIP_REFIT_GROWTH: refit is kept while (sum of node areas / root area) stays below this multiple

@@ -776,7 +776,9 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                            const int* __restrict__ heavy_count, int count, float radius,
                                                            GatherConst gc, float* __restrict__ rgb, int xcd_chunk,
                                                            float2* __restrict__ p1, const int* __restrict__ sub_queue,
-                                                           const int* __restrict__ sub_count)
+                                                           const int* __restrict__ sub_count, GridDesc gdc,
+                                                           const uint32_t* __restrict__ cell_start_c,
+                                                           const float4* __restrict__ pos_c, uint32_t medium)
 {
 	__shared__ uint32_t s_hist[SEL_BINS];
 	__shared__ uint32_t s_list[SEL_LIST], s_lslot[SEL_LIST];
@@ -820,7 +822,33 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 		if constexpr (PHASE != 2) {
 			int nc_l = 0;
 			float mx_l = 0.0f, bound_l = 0.0f;
-			if (SHELL) {
+			// A point with few photons around it pays for the fine grid's rows (17 x 17 of them, two calls of the run
+			// visitor per 64) and gains nothing from the counted interiors: if its cube on the COARSE grid (5 x 5 rows)
+			// holds at most `medium` photons, all of them are read from there in one go.
+			bool coarse_pass = false;
+			if (SHELL && PHASE == 1 && medium > 0u) {
+				const float rho = radius * 1.0001f + 1e-30f;
+				const int y0 = cell_coord(P.y - rho, gdc.mn[1], gdc.inv_cell, gdc.dim[1]), y1 = cell_coord(P.y + rho, gdc.mn[1], gdc.inv_cell, gdc.dim[1]);
+				const int z0 = cell_coord(P.z - rho, gdc.mn[2], gdc.inv_cell, gdc.dim[2]), z1 = cell_coord(P.z + rho, gdc.mn[2], gdc.inv_cell, gdc.dim[2]);
+				const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+				uint32_t pop = 0;
+				for (int row = lane; row < nrows; row += 64) {
+					const int zr = row / ny, y = y0 + (row - zr * ny), z = z0 + zr;
+					int x0, x1;
+					if (row_chord(gdc, P, rho, y, z, x0, x1)) {
+						const uint32_t rb = (uint32_t)((z * gdc.dim[1] + y) * gdc.dim[0]);
+						pop += cell_start_c[rb + x1 + 1] - cell_start_c[rb + x0];
+					}
+				}
+				coarse_pass = wave_sum_u(pop) <= medium;
+			}
+			if (coarse_pass) {
+				for_each_neighbour_wave<true>(mark, gdc, cell_start_c, pos_c, P, radius, [&](uint32_t, float l2, bool act) {
+					const bool in = act && l2 < r2;
+					nc_l += in ? 1 : 0;
+					mx_l = __uint_as_float(max(__float_as_uint(mx_l), in ? __float_as_uint(l2) : 0u));
+				});
+			} else if (SHELL) {
 				wave_shell_sweep<false>(mark, gd, cell_start, pos, P, radius, r2, 0.0f, nc_l, mx_l, bound_l);
 			} else {
 				for_each_neighbour_wave(mark, gd, cell_start, pos, P, radius, [&](uint32_t, float l2, bool act) {
@@ -1365,6 +1393,10 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	// on the device).  tuning.gather_heavy is the threshold (0: every point with a photon nearby takes
 	// the wave kernel; a huge value: none does) -- the parity tests run both extremes.
 	const uint32_t heavy = ctx->tuning.gather_heavy;
+#ifndef RT_GATHER_MEDIUM   // wave kernel, pass 1: at most this many photons in the coarse cube -> read them all from the coarse grid
+#define RT_GATHER_MEDIUM 4096
+#endif
+	const uint32_t medium = RT_GATHER_MEDIUM;
 	RT_CHECK(ctx->d_heavy.reserve(((size_t)2 * npts + 16) * sizeof(int) + ((size_t)npts + 1) * sizeof(float2)));
 	int* heavy_count = ctx->d_heavy.as<int>();
 	int* sub_count = heavy_count + 1;              // heavy-queue positions left to the general selection kernel
@@ -1396,17 +1428,17 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 #ifdef RT_GATHER_FUSED
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 0>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
 #else
 			const int chunk1 = std::max(1, chunk / RT_GATHER_P1_WAVES), unit1 = 8 * chunk1;
 			const int blocks1 = ((std::min(npts, 64 * 1024) + RT_GATHER_P1_WAVES - 1) / RT_GATHER_P1_WAVES + unit1 - 1) / unit1 * unit1;
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 1>), dim3(blocks1), dim3(64 * RT_GATHER_P1_WAVES), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1, (const int*)nullptr, (const int*)nullptr);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
 #ifdef RT_GATHER_NO_COMMON   // probe builds: every heavy point through the general kernel
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 2>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
 #else
 			// the usual heavy point in the lean kernel; what it declines, in the general one
 			hipLaunchKernelGGL(k_photon_select_common, dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
@@ -1414,13 +1446,13 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 			                   radius, gc, d_rgb, chunk, pass1, sub_queue, sub_count);
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 2>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)sub_queue, (const int*)sub_count);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)sub_queue, (const int*)sub_count, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
 #endif
 #endif
 		} else {
 			hipLaunchKernelGGL((k_photon_gather_wave<false, 0>), dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
 			                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
 		}
 		RT_HIP_CHECK(hipGetLastError());
 	}

@@ -88,7 +88,7 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->auto_accel = env_int("RT_HIP_AUTO_PLOC", 1) ? RT_HIP_ACCEL_PLOC : RT_HIP_ACCEL_LBVH;
 	t->ploc_radius = env_int("RT_HIP_PLOC_RADIUS", 8);
 	t->frame_sync = env_int("RT_HIP_FRAME_SYNC", 0);
-	t->gather_heavy = 1024;
+	t->gather_heavy = 32;
 	if (const char* e = getenv("RT_HIP_GATHER_HEAVY")) t->gather_heavy = (uint32_t)strtoul(e, nullptr, 10);
 	t->extra_lds_bytes = env_int("RT_HIP_EXTRA_LDS", 0);
 	t->gather_fine = env_int("RT_HIP_GATHER_FINE", 1);

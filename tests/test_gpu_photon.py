@@ -59,7 +59,7 @@ def test_emission_is_shard_invariant(oracle_cls):
 @pytest.mark.parametrize("count,radius", [(100, 1.0), (50, 3.0), (7, 0.5)])
 def test_gather_matches_oracle(oracle_cls, count, radius, heavy):
     """Both gather kernels against the oracle: by default a point goes to the wave-per-point kernel when its
-    cube holds more than 1024 photons; tuning.gather_heavy = 0 / huge sends every point one way."""
+    cube holds more than tuning.gather_heavy (32) photons; tuning.gather_heavy = 0 / huge sends every point one way."""
     import raytracer_amd as rt
     sc = scenes.cornell()
     orc = oracle_cls(sc)
