@@ -1095,19 +1095,22 @@ void k_photon_select_common(GridDesc gd, const uint32_t* __restrict__ cell_start
 		const float2 r = p1[h];
 		const int nc = __builtin_amdgcn_readfirstlane(__float_as_int(r.x));
 		const float max_dist2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r.y)));
-		bool common = nc > count;
-		if (common) {
+		bool common = true;
+		// nc <= count: every photon within the radius is taken -- the second sweep alone, with all of them "below the bin"
+		float scale = (float)SEL_BINS / r2, rho_sel = radius;
+		int b = SEL_BINS, need = 0;
+		__syncthreads();   // earlier readers are done with the shared state
+		if (lane == 0) { s_tau = 0xFFFFFFFFu; s_take = 0x7fffffff; }
+		if (nc > count) {
 			// level-0 histogram over [0, top): the count-th is expected near r2 * count / nc (photons lie on surfaces)
 			// If the count-th is not below the range after all (the top bin also counts what lies beyond it), the range
 			// is widened fourfold and the histogram redone: the density around a point is not uniform.
 			float top = fminf(r2, r2 * (4.0f * (float)count / (float)nc));
-			float scale;
 			int hh;
 			for (;;) {
 				scale = (float)SEL_BINS / top;
-				__syncthreads();   // earlier readers are done with the shared state
+				__syncthreads();
 				s_hist[lane] = 0u;
-				if (lane == 0) { s_tau = 0xFFFFFFFFu; s_take = 0x7fffffff; }
 				__syncthreads();
 				const float rho0 = top < r2 ? fminf(radius, rt_sqrtf(top) * 1.001f) : radius;
 				for_each_neighbour_wave<(RT_GATHER_MARKS_COMMON != 0)>(mark, gd, cell_start, pos, P, rho0, [&](uint32_t, float l2, bool act) {
@@ -1118,19 +1121,21 @@ void k_photon_select_common(GridDesc gd, const uint32_t* __restrict__ cell_start
 				if (!(top < r2) || wave_sum_i(lane < SEL_BINS - 1 ? hh : 0) >= count) break;
 				top = fminf(r2, top * 4.0f);
 			}
+			const int pre = (int)wave_scan_add_u32((uint32_t)hh);
+			const uint64_t ge = __ballot(pre >= count) & ~(1ull << (SEL_BINS - 1));
+			b = ge ? __ffsll((unsigned long long)ge) - 1 : SEL_BINS - 1;
+			need = count - (__builtin_amdgcn_readlane(pre, b) - __builtin_amdgcn_readlane(hh, b));
+			if (__builtin_amdgcn_readlane(hh, b) > SEL_LIST) common = false;
+			const float width = 1.0f / scale;
+			const float lo_edge = (float)b * width;
+			float hi_edge = r2;
+			if (b < SEL_BINS - 1) hi_edge = fminf(hi_edge, lo_edge + width * 1.001f + fabsf(lo_edge) * 4e-6f);
+			rho_sel = fminf(radius, rt_sqrtf(hi_edge) * 1.001f);
+		}
+		__syncthreads();
+		{
 			{
-				int pre = (int)wave_scan_add_u32((uint32_t)hh);
-				const uint64_t ge = __ballot(pre >= count) & ~(1ull << (SEL_BINS - 1));
-				const int b = ge ? __ffsll((unsigned long long)ge) - 1 : SEL_BINS - 1;
-				const int need = count - (__builtin_amdgcn_readlane(pre, b) - __builtin_amdgcn_readlane(hh, b));
-				const int pop = __builtin_amdgcn_readlane(hh, b);
-				if (pop > SEL_LIST) common = false;
 				if (common) {
-					const float width = 1.0f / scale;
-					const float lo_edge = (float)b * width;
-					float hi_edge = r2;
-					if (b < SEL_BINS - 1) hi_edge = fminf(hi_edge, lo_edge + width * 1.001f + fabsf(lo_edge) * 4e-6f);
-					const float rho_sel = fminf(radius, rt_sqrtf(hi_edge) * 1.001f);
 					const float denom2 = 2.0f * max_dist2;
 					auto contribution = [&](uint32_t s, float l2) {
 						float w = 1.0f - powf(gc.e, -gc.beta * (l2 / denom2));
