@@ -430,13 +430,15 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
         roof = {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
                 "traffic": counters.get("traffic_bytes_per_launch") if counters else None,
-                "kernel": "k_photon_gather + k_photon_gather_wave (radiance_estimate: one lane per point, one wave per point with more than tuning.gather_heavy photons in its cube)",
+                "kernel": "k_photon_gather + k_photon_gather_wave<pass 1> + k_photon_select_common + k_photon_gather_wave<2> (radiance_estimate, timed as one launch: classification and one lane per sparse point; one wave per point with more than tuning.gather_heavy photons in its cube)",
                 "avg_launch_ms": round(avg_ms, 4), "share_of_frame_gpu_time": share(gat_ms),
                 "points_per_launch": round(points, 1), "photon_visits_per_launch": round(visits, 1),
                 "photon_visits_per_point": round(visits / max(points, 1), 1),
                 "flop_per_visit": GATHER_VISIT_FLOP, "bytes_per_visit": GATHER_VISIT_BYTES,
-                "work_definition": "the mandatory first pass only: every photon of the grid cells within the radius is read once (16 B) "
-                                   "to count the candidates and find max_dist2 (rt_photon_map.cpp:159-169); the selection passes are not credited",
+                "work_definition": "the first pass only, priced as a plain grid walk would do it: one distance test (10 FLOP, 16 B) per photon of the "
+                                   "coarse-grid cells within the radius, to count the candidates and find max_dist2 (rt_photon_map.cpp:159-169). "
+                                   "The kernels do less than that (cells inside the sphere are counted from the cell table, not read) and more "
+                                   "(the selection and the sum, not credited)",
                 "frac_unpacked_peak": round(achieved / VALU_UNPACKED_TFLOPS, 4), "peak_unpacked": VALU_UNPACKED_TFLOPS,
                 "algorithmic_cache_GBs": round(visits * GATHER_VISIT_BYTES / (avg_ms * 1e-3) / 1e9, 1),
                 "algorithmic_cache_note": "16 B x photon visits / launch time: served by L1/L2 (neighbouring points read the same cells), not an HBM rate",

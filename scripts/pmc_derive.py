@@ -2,6 +2,8 @@
 """From a pmc_summary.txt (scripts/pmc_summary.py) to the JSON bench.py reads for its roofline object:
 HBM-side bytes per launch of one kernel and the utilisation figures the counters give.
     pmc_derive.py summary.txt out.json <kernel name in the summary> <workload> <shadows> <accel> "<command>"
+Several kernel names joined by '+' (the photon gather is four kernels, timed and priced as one launch): their per-dispatch
+means are added.
 """
 import hashlib, json, os, re, sys
 
@@ -10,9 +12,9 @@ sys.path.insert(0, ROOT)
 summary, out_path, kernel, workload, shadows, accel, command = sys.argv[1:8]
 vals = {}
 for line in open(summary):
-    m = re.match(r"(\S+)\s+(\S+)\s+dispatches=(\d+)\s+mean=([0-9.e+-]+)", line)
-    if m and m.group(1) == kernel:
-        vals[m.group(2)] = float(m.group(4))
+    m = re.match(r"(.+?)\s+(\S+)\s+dispatches=(\d+)\s+mean=([0-9.e+-]+)", line)   # kernel names may hold a blank (<true, 1>)
+    if m and m.group(1) in kernel.split("+"):
+        vals[m.group(2)] = vals.get(m.group(2), 0.0) + float(m.group(4))
 from bench import kernel_source_hash
 SIMDS, TAS, XCDS = 1024, 256, 8
 out = {"kernel": kernel, "workload": workload, "shadows": shadows, "accel": accel, "command": command,

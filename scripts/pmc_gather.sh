@@ -16,8 +16,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for path in sys.argv[1:]:
     for row in csv.DictReader(open(path)):
         k = row["Kernel_Name"]
-        if "photon_gather" not in k: continue
-        name = "wave<1>" if "wave<true, 1>" in k else "wave<2>" if "wave<true, 2>" in k else "wave<0>" if "gather_wave" in k else "lane"
+        if "photon_gather" not in k and "photon_select" not in k: continue
+        name = ("select" if "select_common" in k else "wave<1>" if "wave<true, 1>" in k else "wave<2>" if "wave<true, 2>" in k
+                else "wave<0>" if "gather_wave" in k else "lane")
         a = acc[name][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
 for name, m in sorted(acc.items()):
     v = {k: x[0] / max(x[1], 1) for k, x in m.items()}
