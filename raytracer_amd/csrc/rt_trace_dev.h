@@ -81,6 +81,9 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 		const int EXIT = 0x7fffffff;
 		int cur = (sv.num_tris == 1) ? ~0 : 0;
 		int sp = 0;
+#ifdef RT_STACK_TOP_REG
+		int top = 0;
+#endif
 #ifdef RT_SHARE_OCCLUDER
 		int shares_left = RT_SHARE_OCCLUDER;
 #endif
@@ -99,7 +102,14 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 				slab2(rp, w0, w1, ANY ? sv.tp.t_max : best.t, hl, hr, tl, tr);
 				const bool right_first = hr && (!hl || tr < tl);
 				if (hl && hr) {
+#ifdef RT_STACK_TOP_REG
+					// the newest entry stays in a register: a pop then has its node at once, and the load of the entry
+					// below it runs under the next node's fetch
+					if (sp > 0) stack_push(sv, stack, stride, sp - 1, top);
+					top = right_first ? ch.x : ch.y;
+#else
 					stack_push(sv, stack, stride, sp, right_first ? ch.x : ch.y);
+#endif
 					++sp;
 				}
 				cur = right_first ? ch.y : ch.x;
@@ -142,7 +152,11 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 #endif
 			if (pop) {
 				if (sp == 0) cur = EXIT;
+#ifdef RT_STACK_TOP_REG
+				else { --sp; cur = top; if (sp > 0) top = stack_pop(sv, stack, stride, sp - 1); }
+#else
 				else { --sp; cur = stack_pop(sv, stack, stride, sp); }
+#endif
 			}
 		}
 	}
