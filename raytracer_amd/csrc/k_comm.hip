@@ -8,6 +8,7 @@
 // Both collectives are enqueued on the context's own stream, so they are ordered against its kernels by the
 // stream itself: no host synchronisation brackets them.
 #include <dlfcn.h>
+#include <mutex>
 #include <rccl/rccl.h>
 
 #include "rt_ctx.h"
@@ -28,8 +29,11 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+std::mutex g_rccl_mutex;   // contexts of different threads may ask for RCCL at the same time
+
 int load_rccl()
 {
+	std::lock_guard<std::mutex> lock(g_rccl_mutex);
 	if (g_rccl.lib) return RT_HIP_OK;
 	const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
 	void* lib = nullptr;
@@ -217,12 +221,15 @@ int rt_hip_photon_generate_multi(rt_hip_ctx* ctx, int photons_per_light, int64_t
 	float* full = ctx->d_mg_photons.as<float>();
 	if (mine > 0) RT_HIP_CHECK(hipMemcpyAsync(full + 9 * off[rank], ctx->d_photon_emit.p, (size_t)mine * 36, hipMemcpyDeviceToDevice, st));
 	RT_NCCL_CHECK(g_rccl.GroupStart());
-	for (int r = 0; r < nranks; ++r) {
+	ncclResult_t posted = ncclSuccess;   // a failed call must not leave the group open
+	for (int r = 0; r < nranks && posted == ncclSuccess; ++r) {
 		if (r == rank) continue;
-		if (mine > 0) RT_NCCL_CHECK(g_rccl.Send(ctx->d_photon_emit.p, (size_t)mine * 9, ncclFloat32, r, (ncclComm_t)ctx->comm, st));
-		if (cnt[r] > 0) RT_NCCL_CHECK(g_rccl.Recv(full + 9 * off[r], (size_t)cnt[r] * 9, ncclFloat32, r, (ncclComm_t)ctx->comm, st));
+		if (mine > 0) posted = g_rccl.Send(ctx->d_photon_emit.p, (size_t)mine * 9, ncclFloat32, r, (ncclComm_t)ctx->comm, st);
+		if (posted == ncclSuccess && cnt[r] > 0) posted = g_rccl.Recv(full + 9 * off[r], (size_t)cnt[r] * 9, ncclFloat32, r, (ncclComm_t)ctx->comm, st);
 	}
-	RT_NCCL_CHECK(g_rccl.GroupEnd());
+	const ncclResult_t ended = g_rccl.GroupEnd();
+	RT_NCCL_CHECK(posted);
+	RT_NCCL_CHECK(ended);
 	RT_CHECK(rt_photon_build_grid(ctx, full, all));
 	*out_stored = all;
 	return RT_HIP_OK;
