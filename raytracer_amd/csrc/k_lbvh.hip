@@ -396,18 +396,14 @@ __device__ __forceinline__ uint32_t quant_hi(float v, float org, float scale)
 // list == nullptr: every internal node, boxes already in `slots` (the builders that make boxes as they go).
 // list != nullptr: the `count` nodes of one tree level; each also writes its own box = the union of its children's
 // (the level-by-level refit), so that the next launch, one level up, finds it.
-__global__ __launch_bounds__(256) void k_emit_nodes(BoxSlot* __restrict__ slots, int n, const int* __restrict__ list, int count,
-                                                    const int* __restrict__ left, const int* __restrict__ right,
-                                                    const int* __restrict__ node_parent, BvhNode* __restrict__ nodes,
-                                                    QFrame qf, QNode* __restrict__ qnodes)
+__device__ __forceinline__ void emit_node(BoxSlot* __restrict__ slots, int n, int i, bool own_box, const int* __restrict__ left,
+                                          const int* __restrict__ right, const int* __restrict__ node_parent,
+                                          BvhNode* __restrict__ nodes, const QFrame& qf, QNode* __restrict__ qnodes)
 {
-	int k = blockIdx.x * 256 + threadIdx.x;
-	if (k >= count) return;
-	const int i = list ? list[k] : k;
 	int lc = left[i], rc = right[i];
 	const BoxSlot* l = (lc >= 0) ? (slots + lc) : (slots + (n - 1) + (~lc));
 	const BoxSlot* r = (rc >= 0) ? (slots + rc) : (slots + (n - 1) + (~rc));
-	if (list) {
+	if (own_box) {
 		BoxSlot* me = slots + i;
 		for (int a = 0; a < 3; ++a) { me->mn[a] = fminf(l->mn[a], r->mn[a]); me->mx[a] = fmaxf(l->mx[a], r->mx[a]); }
 	}
@@ -426,6 +422,37 @@ __global__ __launch_bounds__(256) void k_emit_nodes(BoxSlot* __restrict__ slots,
 	qn.w0 = make_uint4(lq[0] | lq[3] << 16, lq[1] | lq[4] << 16, lq[2] | lq[5] << 16, rq[0] | rq[3] << 16);
 	qn.w1 = make_uint4(rq[1] | rq[4] << 16, rq[2] | rq[5] << 16, (uint32_t)lc, (uint32_t)rc);
 	qnodes[i] = qn;
+}
+
+__global__ __launch_bounds__(256) void k_emit_nodes(BoxSlot* __restrict__ slots, int n, const int* __restrict__ list, int count,
+                                                    const int* __restrict__ left, const int* __restrict__ right,
+                                                    const int* __restrict__ node_parent, BvhNode* __restrict__ nodes,
+                                                    QFrame qf, QNode* __restrict__ qnodes)
+{
+	int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= count) return;
+	emit_node(slots, n, list ? list[k] : k, list != nullptr, left, right, node_parent, nodes, qf, qnodes);
+}
+
+// The top of the tree in ONE launch: levels top.last down to 0, each at most TOP_BLOCK nodes, by one workgroup with a
+// barrier between levels (a launch per level costs ~8 us and the upper levels hold a handful of nodes each).
+constexpr int TOP_BLOCK = 1024;
+constexpr int TOP_LEVELS = 32;
+struct TopLevels {
+	int last;                    // deepest level handled here
+	int offset[TOP_LEVELS + 1];  // level d = list[offset[d], offset[d + 1])
+};
+__global__ __launch_bounds__(TOP_BLOCK) void k_emit_nodes_top(BoxSlot* __restrict__ slots, int n, const int* __restrict__ list,
+                                                              TopLevels top, const int* __restrict__ left,
+                                                              const int* __restrict__ right, const int* __restrict__ node_parent,
+                                                              BvhNode* __restrict__ nodes, QFrame qf, QNode* __restrict__ qnodes)
+{
+	for (int d = top.last; d >= 0; --d) {
+		for (int k = top.offset[d] + threadIdx.x; k < top.offset[d + 1]; k += TOP_BLOCK)
+			emit_node(slots, n, list[k], true, left, right, node_parent, nodes, qf, qnodes);
+		__threadfence_block();
+		__syncthreads();
+	}
 }
 
 __global__ __launch_bounds__(256) void k_permute_tris(const TriIsect* __restrict__ in, const uint32_t* __restrict__ order,
@@ -525,12 +552,22 @@ static int refit_by_levels(rt_hip_ctx* ctx, int n, float pad, const uint32_t* or
 	hipStream_t st = ctx->stream;
 	hipLaunchKernelGGL(k_leaf_slots, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad, slots);
 	const int* level_nodes = ctx->d_level_nodes.as<int>();
-	for (int d = (int)ctx->level_offsets.size() - 2; d >= 0; --d) {
+	// the levels from the root down to the first one with more than TOP_BLOCK nodes go into one launch at the end
+	const int nlevels = (int)ctx->level_offsets.size() - 1;
+	TopLevels top;
+	top.last = -1;
+	while (top.last + 1 < nlevels && top.last + 1 < TOP_LEVELS &&
+	       ctx->level_offsets[top.last + 2] - ctx->level_offsets[top.last + 1] <= TOP_BLOCK) ++top.last;
+	for (int d = 0; d <= TOP_LEVELS; ++d) top.offset[d] = ctx->level_offsets[std::min(d, nlevels)];
+	for (int d = nlevels - 1; d > top.last; --d) {
 		const int lo = ctx->level_offsets[d], cnt = ctx->level_offsets[d + 1] - lo;
 		if (cnt <= 0) continue;
 		hipLaunchKernelGGL(k_emit_nodes, dim3((cnt + 255) / 256), dim3(256), 0, st, slots, n, level_nodes + lo, cnt, left, right,
 		                   node_parent, ctx->d_nodes.as<BvhNode>(), ctx->qframe, ctx->d_qnodes.as<QNode>());
 	}
+	if (top.last >= 0)
+		hipLaunchKernelGGL(k_emit_nodes_top, dim3(1), dim3(TOP_BLOCK), 0, st, slots, n, level_nodes, top, left, right, node_parent,
+		                   ctx->d_nodes.as<BvhNode>(), ctx->qframe, ctx->d_qnodes.as<QNode>());
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }

@@ -204,6 +204,8 @@ struct GatherConst {
 	float alpha, beta, e, gauss_denom, two_pi;
 };
 
+__device__ __forceinline__ float bound_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }   // for conservative bounds only
+
 // The x-cells of grid row (y, z) that can hold a photon within rho of P: the row's distance from P in the
 // yz-plane bounds the chord of the sphere along x.  false: the whole row is out of reach.
 __device__ __forceinline__ bool row_chord(const GridDesc& gd, f3 P, float rho, int y, int z, int& x0, int& x1)
@@ -221,7 +223,8 @@ __device__ __forceinline__ bool row_chord(const GridDesc& gd, f3 P, float rho, i
 	dy = fmaxf(dy * 0.9999f - slack, 0.0f); dz = fmaxf(dz * 0.9999f - slack, 0.0f);
 	const float h2 = rho * rho - (dy * dy + dz * dz);
 	if (h2 < 0.0f) return false;
-	const float half = rt_sqrtf(h2) * 1.0001f + slack;
+	// bound_sqrtf: v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence; the margins below are 1e-4 relative
+	const float half = bound_sqrtf(h2) * 1.0001f + slack;
 	x0 = cell_coord(P.x - half, gd.mn[0], gd.inv_cell, gd.dim[0]);
 	x1 = cell_coord(P.x + half, gd.mn[0], gd.inv_cell, gd.dim[0]);
 	return true;
@@ -531,7 +534,7 @@ __device__ __forceinline__ void wave_shell_sweep(uint32_t* mark, const GridDesc&
 					const float dzf = fmaxf(fabsf(zlo - P.z), fabsf(zlo + gd.cell - P.z)) + slack;
 					const float h2 = rin * rin - (dyf * dyf + dzf * dzf);
 					if (h2 > 0.0f) {
-						const float half = rt_sqrtf(h2) * 0.9999f - slack;
+						const float half = bound_sqrtf(h2) * 0.9999f - slack;
 						int xi0 = (int)ceilf((P.x - half - gd.mn[0]) * gd.inv_cell + 1e-3f);
 						int xi1 = (int)floorf((P.x + half - gd.mn[0]) * gd.inv_cell - 1e-3f) - 1;
 						xi0 = max(xi0, max(x0, 1)); xi1 = min(xi1, min(x1, gd.dim[0] - 2));
@@ -1402,7 +1405,8 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 #define RT_GATHER_MEDIUM 4096
 #endif
 	const uint32_t medium = RT_GATHER_MEDIUM;
-	RT_CHECK(ctx->d_heavy.reserve(((size_t)2 * npts + 16) * sizeof(int) + ((size_t)npts + 1) * sizeof(float2)));
+	// counts (16 ints) | heavy queue (npts, padded to even) | pass-1 results (npts + 1 float2) | sub-queue (npts)
+	RT_CHECK(ctx->d_heavy.reserve(((size_t)2 * npts + 16 + 2) * sizeof(int) + ((size_t)npts + 1) * sizeof(float2)));
 	int* heavy_count = ctx->d_heavy.as<int>();
 	int* sub_count = heavy_count + 1;              // heavy-queue positions left to the general selection kernel
 	int* heavy_queue = heavy_count + 16;

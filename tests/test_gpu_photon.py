@@ -56,7 +56,8 @@ def test_emission_is_shard_invariant(oracle_cls):
 
 
 @pytest.mark.parametrize("heavy", [None, 0, 4000000000], ids=["default-split", "all-wave", "all-lane"])
-@pytest.mark.parametrize("count,radius", [(100, 1.0), (50, 3.0), (7, 0.5)])
+# (400, ...): more photons wanted than the wave kernels queue in LDS for the sum (256): the overflow branch sums on the spot
+@pytest.mark.parametrize("count,radius", [(100, 1.0), (50, 3.0), (7, 0.5), (400, 3.0), (400, 0.7)])
 def test_gather_matches_oracle(oracle_cls, count, radius, heavy):
     """Both gather kernels against the oracle: by default a point goes to the wave-per-point kernel when its
     cube holds more than tuning.gather_heavy (32) photons; tuning.gather_heavy = 0 / huge sends every point one way."""
