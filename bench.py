@@ -79,6 +79,8 @@ def offline_counters(workload, shadow_mode, accel, photons):
             c = json.load(f)
         want = dict(workload=workload + ("+photons" if photons else ""), shadows=shadow_mode, accel=accel)
         have = dict(workload=c.get("workload"), shadows=c.get("shadows", "corrected"), accel=c.get("accel", "ploc"))
+        if photons:   # the counter profile of a photon-mapped frame belongs to one photon count
+            want["photons_per_light"] = int(photons); have["photons_per_light"] = c.get("photons_per_light")
         if want != have:
             return None, "profiles/%s is for %s, this run is %s" % (name, have, want)
         if c.get("kernel_source_hash") != kernel_source_hash(photons):
@@ -416,7 +418,7 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
     tris_any = cs["census_tris_any"] / max(cs["census_rays_any"], 1)
     nodes_clo = cs["census_nodes_closest"] / max(cs["census_rays_closest"], 1)
     tris_clo = cs["census_tris_closest"] / max(cs["census_rays_closest"], 1)
-    counters, counters_note = offline_counters(args.workload, args.shadow_mode, args.accel, args.photons > 0) if world == 1 else (None, "N > 1: no counter profile")
+    counters, counters_note = offline_counters(args.workload, args.shadow_mode, args.accel, args.photons) if world == 1 else (None, "N > 1: no counter profile")
 
     share = lambda ms: round(ms / frame_ms, 4) if frame_ms > 0 else None
     if gat_ms > max(any_ms, clo_ms):
