@@ -579,6 +579,34 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
         g.set_config(shadow_t_max=1.0)
         cfg["literal_shadows_ms_per_frame"] = round(ms, 4)
         cfg["literal_shadows_mrays_per_s"] = round(mr, 1)
+    # SURVEY 8d's incoherent stress set: 2^22 rays, uniform origins in the scene's box, uniform directions, seed 7,
+    # through the batch entries (rt_hip_trace_closest_device / rt_hip_trace_any_device), HIP-event time of the kernels
+    try:
+        n = 1 << 22
+        V = np.concatenate([np.asarray(me.verts, np.float32).reshape(-1, 3) for me in scene.meshes], 0)
+        lo = torch.from_numpy(V.min(0)).to(dev); hi = torch.from_numpy(V.max(0)).to(dev)
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        org = (lo + (hi - lo) * torch.rand((n, 3), generator=gen).to(dev)).contiguous()
+        d = torch.randn((n, 3), generator=gen).to(dev)
+        d = (d / d.norm(dim=1, keepdim=True)).contiguous()
+        hits = torch.zeros(n * 4, dtype=torch.float32, device=dev)
+        occ = torch.zeros(n, dtype=torch.uint8, device=dev)
+        g.set_config(profile=1)
+        for name, call in (("closest", lambda: g.trace_closest_device(org, d, n, hits)), ("any", lambda: g.trace_any_device(org, d, n, occ))):
+            call(); g.sync(); g.reset_stats()
+            for _ in range(5):
+                call()
+            g.sync()
+            st = g.stats()
+            ms = (st["closest_ms"] if name == "closest" else st["any_ms"]) / 5
+            cfg["incoherent_%s_mrays_per_s" % name] = round(n / (ms * 1e-3) / 1e6, 1)
+        prim = hits.view(torch.int32).view(-1, 4)[:, 0]
+        cfg["incoherent_note"] = ("SURVEY 8d stress set: 2^22 rays, origins uniform in the scene's box, directions uniform on the sphere, seed 7; "
+                                  "kernel time of rt_hip_trace_closest_device / rt_hip_trace_any_device (t_max 1e6), %.0f %% of the rays hit" %
+                                  (100.0 * float((prim != -1).float().mean())))
+        del org, d, hits, occ
+    except Exception as e:   # an extra must not take the line with it
+        cfg["incoherent_note"] = "not measured: %r" % (e,)
     # north_star's target: ~1M triangles at 1080p, same shading
     target = None
     if args.workload == "atrium-262k-1080p":
