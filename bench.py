@@ -530,6 +530,19 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
     cfg["ms_per_frame_host_to_host"] = round(float(np.median(ts)), 3)
     cfg["host_to_host_note"] = ("rt_hip_render_frame: %.1f MB G-buffer up with hipMemcpyAsync from pinned host memory, frame, %.1f MB image down; "
                                 "median of 20; PCIe-bound, never `value`" % (npix * 28 / 1e6, npix * 4 / 1e6))
+    # one frame at a time, as SURVEY 8d words the GPU timing (3 warm-up + 20 timed, median and p95): call -> image complete,
+    # host clock around rt_hip_render_frame_device + stream sync, G-buffer and image resident in HBM
+    ts = []
+    for i in range(23):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.render_frame_device(gb_p, gb_n, W, H, out_dev)
+        g.sync()
+        if i >= 3:
+            ts.append((time.perf_counter() - t0) * 1e3)
+    cfg["ms_per_frame_single_median"] = round(float(np.median(ts)), 4)
+    cfg["ms_per_frame_single_p95"] = round(float(np.percentile(ts, 95)), 4)
+    cfg["single_frame_note"] = "one frame per call with a stream sync after each (latency of a lone frame), median and 95th percentile of 20"
     # The frame with the scene brought up to date first, on a context that applies model matrices as processRays does
     # (use_model_mat = 1; the scene's matrices are identities, so the geometry and the image are the same).
     render = type(g).render_tiles_batch_device.__wrapped__
