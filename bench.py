@@ -530,6 +530,24 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
     cfg["ms_per_frame_host_to_host"] = round(float(np.median(ts)), 3)
     cfg["host_to_host_note"] = ("rt_hip_render_frame: %.1f MB G-buffer up with hipMemcpyAsync from pinned host memory, frame, %.1f MB image down; "
                                 "median of 20; PCIe-bound, never `value`" % (npix * 28 / 1e6, npix * 4 / 1e6))
+    # the same host-to-host frames through the pipeline entry (rt_hip_frame_enqueue: uploads and downloads on streams of
+    # their own, one frame enqueued ahead): what a host-buffer caller that draws frame after frame gets per frame
+    try:
+        h_o2 = torch.zeros(npix * 4, dtype=torch.uint8).pin_memory()
+        outs = (h_o, h_o2)
+        n = 40
+        g.frame_enqueue_host(h_p, h_n, W, H, outs[0]); g.frame_finish()          # warm: staging buffers, streams
+        t0 = time.perf_counter()
+        g.frame_enqueue_host(h_p, h_n, W, H, outs[0])
+        for i in range(1, n):
+            g.frame_enqueue_host(h_p, h_n, W, H, outs[i & 1])
+            g.frame_finish()
+        g.frame_finish()
+        cfg["ms_per_frame_host_to_host_pipelined"] = round((time.perf_counter() - t0) * 1e3 / n, 3)
+        cfg["host_to_host_pipelined_note"] = ("rt_hip_frame_enqueue / rt_hip_frame_finish, %d frames, one enqueued ahead: frame k + 1's G-buffer crosses "
+                                              "PCIe under frame k's kernels; wall time / frames" % n)
+    except Exception as e:
+        cfg["host_to_host_pipelined_note"] = "not measured: %r" % (e,)
     # one frame at a time, as SURVEY 8d words the GPU timing (3 warm-up + 20 timed, median and p95): call -> image complete,
     # host clock around rt_hip_render_frame_device + stream sync, G-buffer and image resident in HBM
     ts = []

@@ -362,6 +362,14 @@ int rt_hip_unpack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_packed, int wid
 int rt_hip_frame_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width, int height,
                                 uint8_t* d_rgba_out);
 int rt_hip_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays);
+/* The pipeline fed from HOST memory (what rt_hip_render_frame does, rt_raytracer.h:58's caller hands host arrays): the G-buffer
+ * is uploaded on a copy stream of its own, the frame waits for it, the image goes back on a third stream, so with one frame
+ * enqueued ahead the PCIe legs of frame k + 1 and k - 1 run under the kernels of frame k.  The three buffers must stay valid
+ * and untouched until rt_hip_frame_finish has returned for this frame, and should be pinned (hipHostMalloc /
+ * hipHostRegister): with pageable memory the copies are staged by the runtime and the overlap is lost, not the result.
+ * Frames enqueued through either entry finish in order through the same rt_hip_frame_finish. */
+int rt_hip_frame_enqueue(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float* gbuf_nrm_rgba, int width, int height,
+                         uint8_t* rgba_out);
 /* Secondary rays issued by the last frame call (shadow + reflection + refraction). */
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx);
 

@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device", "rt_hip_gbuffer_select_noalloc_device",
-    "rt_hip_frame_enqueue_device", "rt_hip_frame_finish", "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device",
+    "rt_hip_frame_enqueue_device", "rt_hip_frame_enqueue", "rt_hip_frame_finish", "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device",
     "rt_hip_photon_generate_multi", "rt_hip_set_model_mats", "rt_hip_photon_generate", "rt_hip_photon_get", "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
 ]
 
@@ -150,6 +150,7 @@ def load_library() -> C.CDLL:
     L.rt_hip_render_frame_device.argtypes = [P, P, P, C.c_int, C.c_int, P]
     L.rt_hip_render_tiles_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_frame_enqueue_device.argtypes = [P, P, P, C.c_int, C.c_int, P]
+    L.rt_hip_frame_enqueue.argtypes = [P, P, P, C.c_int, C.c_int, P]
     L.rt_hip_frame_finish.argtypes = [P, C.POINTER(C.c_int64)]
     L.rt_hip_last_frame_rays.argtypes = [P]
     L.rt_hip_last_frame_rays.restype = C.c_int64
@@ -458,6 +459,12 @@ class RtHip:
 
     def render_frame_device(self, d_pos_rgb, d_nrm_rgba, w, h, d_rgba):
         self._ck(self.lib.rt_hip_render_frame_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, _dptr(d_rgba)))
+
+    def frame_enqueue_host(self, h_pos_rgb, h_nrm_rgba, w, h, h_rgba):
+        """rt_hip_frame_enqueue: the pipeline fed from (pinned) host tensors / arrays; they must stay alive and untouched
+        until frame_finish() has returned for this frame."""
+        ptr = lambda a: C.c_void_p(a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data)
+        self._ck(self.lib.rt_hip_frame_enqueue(self.h, ptr(h_pos_rgb), ptr(h_nrm_rgba), w, h, ptr(h_rgba)))
 
     def frame_enqueue_device(self, d_pos_rgb, d_nrm_rgba, w, h, d_rgba):
         """Queue a whole frame without waiting for it (at most two unfinished); frame_finish() completes the oldest."""

@@ -1797,6 +1797,7 @@ int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
 	PendingFrame* pf = &ctx->pending[ctx->pending_head];
 	bool overflowed = false;
 	RT_CHECK(frame_async_finish(ctx, pf, &overflowed));
+	ctx->frame_redone = overflowed;
 	if (overflowed) {
 		// exceptional: the frame again, on the driver that sizes every level on the host (behind whatever is still queued)
 		RT_CHECK(render_frame_sync(ctx, pf->fs.pos[0], pf->fs.nrm[0], pf->fs.uv[0], pf->w, pf->h, pf->tile, pf->rank, pf->nranks, pf->fs.rgba[0]));

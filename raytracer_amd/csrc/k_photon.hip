@@ -787,7 +787,7 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 	__shared__ uint32_t s_list[SEL_LIST], s_lslot[SEL_LIST];
 	__shared__ float s_bl2[SEL_BELOW];        // photons below the count-th's bin: squared distance and sorted slot
 	__shared__ uint32_t s_bslot[SEL_BELOW];
-	__shared__ uint32_t s_m, s_tau;
+	__shared__ uint32_t s_tau;
 	__shared__ int s_take;
 	__shared__ uint32_t s_mark[PHASE == 1 ? RT_GATHER_P1_WAVES : 1][64];   // wave_visit_runs' byte table, one per wave
 	uint32_t* mark = s_mark[PHASE == 1 ? (threadIdx.x >> 6) : 0];
@@ -940,7 +940,7 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 				// differ) is certainly selected and is summed (:178-197) at once; the photons of the count-th's own bin
 				// go to a list in LDS with their slots, are ranked there, and the selected ones are summed from the list.
 				const int upto = nlv;
-				if (lane == 0) { s_m = 0u; s_tau = 0xFFFFFFFFu; s_take = 0x7fffffff; }
+				if (lane == 0) { s_tau = 0xFFFFFFFFu; s_take = 0x7fffffff; }
 				__syncthreads();
 				const float denom2 = 2.0f * max_dist2;
 				auto contribution = [&](uint32_t s, float l2) {

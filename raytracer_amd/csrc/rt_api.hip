@@ -384,9 +384,14 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	if (ctx->h_offsets) (void)hipHostFree(ctx->h_offsets);
 	if (ctx->h_small) (void)hipHostFree(ctx->h_small);
 	if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
+	if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
+	if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
 	for (int k = 0; k < 2; ++k) {
 		if (ctx->pending[k].ev0) (void)hipEventDestroy(ctx->pending[k].ev0);
 		if (ctx->pending[k].ev1) (void)hipEventDestroy(ctx->pending[k].ev1);
+		for (hipEvent_t e : {ctx->pending[k].ev_up, ctx->pending[k].ev_done, ctx->pending[k].ev_down})
+			if (e) (void)hipEventDestroy(e);
+		ctx->d_pipe_pos[k].release(); ctx->d_pipe_nrm[k].release(); ctx->d_pipe_img[k].release();
 	}
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -906,10 +911,61 @@ int rt_hip_frame_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, co
 	return rt_frame_enqueue(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, d_rgba_out);
 }
 
+// The same pipeline fed from host memory: the G-buffer of frame k + 1 crosses PCIe while frame k is traced, and frame k's
+// image goes back while frame k + 1 is traced.  Three streams (up, the context's, down) chained by events per slot.
+int rt_hip_frame_enqueue(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float* gbuf_nrm_rgba, int width, int height, uint8_t* rgba_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !gbuf_pos_rgb || !gbuf_nrm_rgba || !rgba_out) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	if (ctx->pending_count >= 2) { rt_set_error("two frames are already enqueued: rt_hip_frame_finish() one first"); return RT_HIP_ERR_STATE; }
+	const int slot = (ctx->pending_head + ctx->pending_count) & 1;
+	PendingFrame* pf = &ctx->pending[slot];
+	if (!ctx->up_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+	if (!ctx->down_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+	if (!pf->ev_up) RT_HIP_CHECK(hipEventCreateWithFlags(&pf->ev_up, hipEventDisableTiming));
+	if (!pf->ev_done) RT_HIP_CHECK(hipEventCreateWithFlags(&pf->ev_done, hipEventDisableTiming));
+	if (!pf->ev_down) RT_HIP_CHECK(hipEventCreateWithFlags(&pf->ev_down, hipEventDisableTiming));
+	const size_t npix = (size_t)width * height;
+	RT_CHECK(ctx->d_pipe_pos[slot].reserve(npix * 12));
+	RT_CHECK(ctx->d_pipe_nrm[slot].reserve(npix * 16));
+	RT_CHECK(ctx->d_pipe_img[slot].reserve(npix * 4));
+	// the slot's staging is free: its previous frame was finished before the slot could be taken again
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_pipe_pos[slot].p, gbuf_pos_rgb, npix * 12, hipMemcpyHostToDevice, ctx->up_stream));
+	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_pipe_nrm[slot].p, gbuf_nrm_rgba, npix * 16, hipMemcpyHostToDevice, ctx->up_stream));
+	RT_HIP_CHECK(hipEventRecord(pf->ev_up, ctx->up_stream));
+	RT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, pf->ev_up, 0));
+	RT_CHECK(rt_frame_enqueue(ctx, ctx->d_pipe_pos[slot].as<float>(), ctx->d_pipe_nrm[slot].as<float>(), width, height,
+	                          ctx->d_pipe_img[slot].as<uint8_t>()));
+	RT_HIP_CHECK(hipEventRecord(pf->ev_done, ctx->stream));
+	RT_HIP_CHECK(hipStreamWaitEvent(ctx->down_stream, pf->ev_done, 0));
+	RT_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_pipe_img[slot].p, npix * 4, hipMemcpyDeviceToHost, ctx->down_stream));
+	RT_HIP_CHECK(hipEventRecord(pf->ev_down, ctx->down_stream));
+	pf->host = true;
+	pf->h_rgba = rgba_out;
+	pf->img_bytes = npix * 4;
+	return RT_HIP_OK;
+}
+
 int rt_hip_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
 {
 	RT_CHECK(check_ctx(ctx));
-	return rt_frame_finish(ctx, out_rays);
+	PendingFrame* pf = ctx->pending_count > 0 ? &ctx->pending[ctx->pending_head] : nullptr;
+	const bool host = pf && pf->host;
+	hipEvent_t ev_down = host ? pf->ev_down : nullptr;
+	uint8_t* h_rgba = host ? pf->h_rgba : nullptr;
+	const uint8_t* d_img = host ? pf->fs.rgba[0] : nullptr;
+	const size_t bytes = host ? pf->img_bytes : 0;
+	if (pf) pf->host = false;
+	RT_CHECK(rt_frame_finish(ctx, out_rays));
+	if (host) {
+		RT_HIP_CHECK(hipEventSynchronize(ev_down));
+		if (ctx->frame_redone) {
+			// the frame was rendered again after the download had been queued (a level overflowed its bound): fetch it again
+			RT_HIP_CHECK(hipMemcpyAsync(h_rgba, d_img, bytes, hipMemcpyDeviceToHost, ctx->stream));
+			RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		}
+	}
+	return RT_HIP_OK;
 }
 
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx) { return ctx ? ctx->last_frame_rays : 0; }

@@ -116,6 +116,11 @@ struct PendingFrame {
 	// what a repeat on the synchronous driver needs (a level overflowed its bound)
 	FrameSet fs;
 	int w = 0, h = 0, tile = 0, rank = 0, nranks = 1, packed = 0;
+	// rt_hip_frame_enqueue (host buffers): the copies run on streams of their own, ordered against the frame by events
+	bool host = false;
+	hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_down = nullptr;
+	uint8_t* h_rgba = nullptr;
+	size_t img_bytes = 0;
 };
 
 struct rt_hip_ctx {
@@ -129,7 +134,10 @@ struct rt_hip_ctx {
 	size_t trace_events_collected = 0;                            // [collected, used) are still to be folded into the stats
 	PendingFrame pending[2];                                      // the frame pipeline (rt_hip_frame_enqueue_device / _finish)
 	int pending_head = 0, pending_count = 0;                      // oldest slot, frames enqueued and not finished
+	bool frame_redone = false;                                    // the last rt_frame_finish rendered its frame again (level overflow)
 	void* h_pipe = nullptr;                                       // pinned: 2 x 512 B of frame counters
+	hipStream_t up_stream = nullptr, down_stream = nullptr;       // rt_hip_frame_enqueue: G-buffer up / image down beside the frame's stream
+	DevBuf d_pipe_pos[2], d_pipe_nrm[2], d_pipe_img[2];           // its device staging, one set per pending slot
 	DevBuf d_census, d_spill, d_tile_list;
 	int tile_key[5] = {0, 0, 0, 0, 0};                            // (w, h, tile, rank, nranks) of d_tile_list
 	int tile_count = 0;

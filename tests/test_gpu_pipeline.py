@@ -56,3 +56,49 @@ def test_pipelined_frames_equal_sequential_frames():
     g.frame_enqueue_device(gb[1][0], gb[1][1], w, h, o2)
     assert g.frame_finish() == exp[1][1] and torch.equal(o2, exp[1][0])
     g.close()
+
+
+def test_host_pipeline_equals_host_frames():
+    """rt_hip_frame_enqueue (pinned host buffers, copies on their own streams) against rt_hip_render_frame on the same
+    G-buffers: same images, same ray counts, frames finished in order, mixed with the device-pointer entry."""
+    import torch
+    import raytracer_amd as rt
+    sc = scenes.atrium(8192)
+    g = rt.RtHip(sc, semantics="array", accel=rt.ACCEL_PLOC, bounces=2, do_shadows=1, shadow_t_max=1.0)
+    w, h = 320, 200
+    host, exp = [], []
+    for f in range(5):
+        d_n = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+        d_p = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+        g.render_gbuffer_device(sc.fov - 0.04 * f, w, h, d_n, d_p)
+        g.sync()
+        h_p, h_n = d_p.cpu().pin_memory(), d_n.cpu().pin_memory()
+        img = g.render_frame(h_p.numpy().reshape(-1, 3), h_n.numpy().reshape(-1, 4), w, h)
+        host.append((h_p, h_n, d_p, d_n))
+        exp.append((np.asarray(img).reshape(-1).copy(), g.last_frame_rays()))
+    outs = [torch.full((w * h * 4,), 7, dtype=torch.uint8).pin_memory() for _ in range(5)]
+    d_out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    got = []
+    g.frame_enqueue_host(host[0][0], host[0][1], w, h, outs[0])
+    g.frame_enqueue_host(host[1][0], host[1][1], w, h, outs[1])
+    with pytest.raises(rt.RtHipError, match="already enqueued"):
+        g.frame_enqueue_host(host[2][0], host[2][1], w, h, outs[2])
+    got.append(g.frame_finish())
+    assert np.array_equal(outs[0].numpy(), exp[0][0])        # complete when its finish returns, while frame 1 may still run
+    g.frame_enqueue_host(host[2][0], host[2][1], w, h, outs[2])
+    got.append(g.frame_finish())
+    rt.RtHip.frame_enqueue_device.__wrapped__(g, host[3][2], host[3][3], w, h, d_out)   # a device-pointer frame in between
+    got.append(g.frame_finish())
+    g.frame_enqueue_host(host[4][0], host[4][1], w, h, outs[4])
+    got.append(g.frame_finish())
+    got.append(g.frame_finish())
+    g.sync()
+    assert got == [r for _, r in exp]
+    for f in (0, 1, 2, 4):
+        assert np.array_equal(outs[f].numpy(), exp[f][0]), "image of frame %d" % f
+    assert np.array_equal(d_out.cpu().numpy(), exp[3][0])
+    # pageable memory works too (no overlap, same result)
+    plain = np.full(w * h * 4, 9, np.uint8)
+    g.frame_enqueue_host(host[1][0].numpy().copy(), host[1][1].numpy().copy(), w, h, plain)
+    assert g.frame_finish() == exp[1][1] and np.array_equal(plain, exp[1][0])
+    g.close()
