@@ -530,6 +530,30 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
     cfg["ms_per_frame_host_to_host"] = round(float(np.median(ts)), 3)
     cfg["host_to_host_note"] = ("rt_hip_render_frame: %.1f MB G-buffer up with hipMemcpyAsync from pinned host memory, frame, %.1f MB image down; "
                                 "median of 20; PCIe-bound, never `value`" % (npix * 28 / 1e6, npix * 4 / 1e6))
+    # its legs, as SURVEY 8d lists them (upload, trace + shade, download), each by HIP events around the same copies / frame
+    try:
+        d_p2, d_n2 = torch.empty_like(gb_p), torch.empty_like(gb_n)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        legs = {"upload": [], "frame": [], "download": []}
+        for i in range(13):
+            torch.cuda.synchronize()
+            ev[0].record()
+            d_p2.copy_(h_p, non_blocking=True); d_n2.copy_(h_n, non_blocking=True)
+            ev[1].record()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g.render_frame_device(d_p2, d_n2, W, H, out_dev); g.sync()
+            t_frame = (time.perf_counter() - t0) * 1e3
+            ev[2].record()
+            h_o.copy_(out_dev, non_blocking=True)
+            ev[3].record()
+            torch.cuda.synchronize()
+            if i >= 3:
+                legs["upload"].append(ev[0].elapsed_time(ev[1])); legs["frame"].append(t_frame); legs["download"].append(ev[2].elapsed_time(ev[3]))
+        cfg["host_to_host_legs_ms"] = {k: round(float(np.median(v)), 3) for k, v in legs.items()}
+        del d_p2, d_n2
+    except Exception as e:
+        cfg["host_to_host_legs_ms"] = "not measured: %r" % (e,)
     # the same host-to-host frames through the pipeline entry (rt_hip_frame_enqueue: uploads and downloads on streams of
     # their own, one frame enqueued ahead): what a host-buffer caller that draws frame after frame gets per frame
     try:
