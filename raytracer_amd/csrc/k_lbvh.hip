@@ -219,9 +219,19 @@ __device__ __forceinline__ int ploc_nearest(const CBox* __restrict__ win, int ba
 	return bj;
 }
 
-__global__ __launch_bounds__(PB) void k_ploc_nn(const CBox* __restrict__ cbox, int c, int r, int force, int* __restrict__ nn)
+// The rounds are driven from the DEVICE: the number of clusters, the nodes made so far, which of the two cluster lists is
+// current and the force flag live in `state` (PS_*), every kernel of a round reads them, k_ploc_advance moves them on.  The
+// host queues several rounds at a time and reads the state back once per batch (a read-back per round was half the
+// build: 22 rounds x a stream synchronise).  Rounds queued after the list has shrunk to PTAIL return at once.
+enum { PS_C = 0, PS_CREATED = 1, PS_CUR = 2, PS_FORCE = 3, PS_ROUNDS = 4, PS_ERROR = 5 };
+
+__global__ __launch_bounds__(PB) void k_ploc_nn_d(const CBox* __restrict__ cb0, const CBox* __restrict__ cb1,
+                                                  const int* __restrict__ state, int r, int* __restrict__ nn)
 {
 	__shared__ CBox win[PB + 2 * PR_MAX];
+	const int c = state[PS_C];
+	if (c <= PTAIL || (int)(blockIdx.x * PB) >= c) return;
+	const CBox* cbox = state[PS_CUR] ? cb1 : cb0;
 	const int base = blockIdx.x * PB - r;
 	for (int t = threadIdx.x; t < PB + 2 * r; t += PB) {
 		int g = base + t;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(PB) void k_ploc_nn(const CBox* __restrict__ cbox, i
 	}
 	__syncthreads();
 	int i = blockIdx.x * PB + threadIdx.x;
-	if (i < c) nn[i] = ploc_nearest(win, base, i, c, r, force);
+	if (i < c) nn[i] = ploc_nearest(win, base, i, c, r, state[PS_FORCE]);
 }
 
 // flag: 0 dies (absorbed by its partner), 1 survives unchanged, 2 survives as the new parent node
@@ -261,9 +271,11 @@ __device__ __forceinline__ void block_scan2(bool a, bool b, int& pre_a, int& pre
 	tot_a = ta; tot_b = tb;
 }
 
-__global__ __launch_bounds__(PB) void k_ploc_count(const int* __restrict__ nn, int c, uint8_t* __restrict__ flag,
-                                                  int2* __restrict__ block_counts)
+__global__ __launch_bounds__(PB) void k_ploc_count_d(const int* __restrict__ nn, const int* __restrict__ state,
+                                                    uint8_t* __restrict__ flag, int2* __restrict__ block_counts)
 {
+	const int c = state[PS_C];
+	if (c <= PTAIL || (int)(blockIdx.x * PB) >= c) return;
 	int i = blockIdx.x * PB + threadIdx.x;
 	int f = ploc_flag(nn, i, c);
 	if (i < c) flag[i] = (uint8_t)f;
@@ -273,8 +285,15 @@ __global__ __launch_bounds__(PB) void k_ploc_count(const int* __restrict__ nn, i
 }
 
 // One workgroup: exclusive scan of the per-block counts in place; totals[0] = survivors.
-__global__ __launch_bounds__(1024) void k_ploc_scan(int2* __restrict__ block_counts, int nb, int* __restrict__ totals)
+// state != nullptr: nb comes from the device-side cluster count (and nothing happens once the list is short).
+__global__ __launch_bounds__(1024) void k_ploc_scan(int2* __restrict__ block_counts, int nb, int* __restrict__ totals,
+                                                   const int* __restrict__ state)
 {
+	if (state) {
+		const int c = state[PS_C];
+		if (c <= PTAIL) return;
+		nb = (c + PB - 1) / PB;
+	}
 	__shared__ int sa[1024], sb[1024];
 	__shared__ int carry_a, carry_b;
 	if (threadIdx.x == 0) { carry_a = 0; carry_b = 0; }
@@ -306,14 +325,21 @@ __device__ __forceinline__ void ploc_link(int id, int a, int b, int* left, int* 
 	if (b >= 0) node_parent[b] = id; else leaf_parent[~b] = id;
 }
 
-__global__ __launch_bounds__(PB) void k_ploc_merge(const int* __restrict__ cl, const CBox* __restrict__ cbox,
-                                                  const int* __restrict__ nn, const uint8_t* __restrict__ flag,
-                                                  const int2* __restrict__ block_prefix, int c, int n, int created,
-                                                  int* __restrict__ cl_out, CBox* __restrict__ cbox_out,
-                                                  int* __restrict__ left, int* __restrict__ right,
-                                                  int* __restrict__ node_parent, int* __restrict__ leaf_parent,
-                                                  BoxSlot* __restrict__ slots)
+__global__ __launch_bounds__(PB) void k_ploc_merge_d(const int* __restrict__ cl0, const int* __restrict__ cl1,
+                                                    const CBox* __restrict__ cb0, const CBox* __restrict__ cb1,
+                                                    const int* __restrict__ nn, const uint8_t* __restrict__ flag,
+                                                    const int2* __restrict__ block_prefix, const int* __restrict__ state, int n,
+                                                    int* __restrict__ left, int* __restrict__ right,
+                                                    int* __restrict__ node_parent, int* __restrict__ leaf_parent,
+                                                    BoxSlot* __restrict__ slots)
 {
+	const int c = state[PS_C];
+	if (c <= PTAIL || (int)(blockIdx.x * PB) >= c) return;
+	const int created = state[PS_CREATED], cur = state[PS_CUR];
+	const int* cl = cur ? cl1 : cl0;
+	const CBox* cbox = cur ? cb1 : cb0;
+	int* cl_out = const_cast<int*>(cur ? cl0 : cl1);
+	CBox* cbox_out = const_cast<CBox*>(cur ? cb0 : cb1);
 	int i = blockIdx.x * PB + threadIdx.x;
 	int f = i < c ? flag[i] : 0;
 	int pa, pb, ta, tb;
@@ -333,6 +359,22 @@ __global__ __launch_bounds__(PB) void k_ploc_merge(const int* __restrict__ cl, c
 		cl_out[pos] = id;
 		cbox_out[pos] = u;
 	}
+}
+
+// End of a round: the survivors become the list.  No progress is only possible with exact distance ties; a forced round
+// pairs neighbours.  A count that grew, or more than halved, is a broken round: PS_ERROR, and the rounds stop.
+__global__ void k_ploc_advance(int* __restrict__ state, const int* __restrict__ totals)
+{
+	const int c = state[PS_C];
+	if (c <= PTAIL) return;
+	const int c_next = totals[0];
+	if (c_next > c || c_next < (c + 1) / 2) { state[PS_ERROR] = c_next + 1; state[PS_C] = 0; return; }
+	const int rounds = state[PS_ROUNDS] + 1;
+	state[PS_ROUNDS] = rounds;
+	state[PS_FORCE] = (c_next == c || rounds > 512) ? 1 : 0;
+	state[PS_CREATED] = state[PS_CREATED] + (c - c_next);
+	state[PS_C] = c_next;
+	state[PS_CUR] = state[PS_CUR] ^ 1;
 }
 
 // The last rounds (c <= PTAIL) in one workgroup, clusters in LDS.
@@ -603,25 +645,31 @@ static int build_ploc(rt_hip_ctx* ctx, int n, float pad, const uint32_t* order, 
 	uint8_t* flag = (uint8_t*)(totals + 16);
 	hipLaunchKernelGGL(k_ploc_init, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_tri_box.as<float4>(), order, n, pad,
 	                   slots, cl[0], cbox[0]);
-	int c = n, created = 0, cur = 0, force = 0, rounds = 0;
-	int* h_tot = (int*)ctx->h_small;
+	int c = n, created = 0, cur = 0;
+	int* h_state = (int*)ctx->h_small;   // pinned
+	int* state = totals + 8;
+	if (c > PTAIL) {
+		const int init[6] = {n, 0, 0, 0, 0, 0};
+		memcpy(h_state, init, sizeof(init));
+		RT_HIP_CHECK(hipMemcpyAsync(state, h_state, sizeof(init), hipMemcpyHostToDevice, st));
+		RT_HIP_CHECK(hipStreamSynchronize(st));   // h_state is read back into below
+	}
+	constexpr int ROUNDS_PER_BATCH = 8;
 	while (c > PTAIL) {
-		const int nb = (c + PB - 1) / PB;
-		hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(PB), 0, st, cbox[cur], c, r, force, nn);
-		hipLaunchKernelGGL(k_ploc_count, dim3(nb), dim3(PB), 0, st, nn, c, flag, block_counts);
-		hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, totals);
-		hipLaunchKernelGGL(k_ploc_merge, dim3(nb), dim3(PB), 0, st, cl[cur], cbox[cur], nn, flag, block_counts, c, n, created,
-		                   cl[cur ^ 1], cbox[cur ^ 1], left, right, node_parent, leaf_parent, slots);
+		const int nb = (c + PB - 1) / PB;         // c only shrinks: the grid of this batch covers all of its rounds
+		for (int k = 0; k < ROUNDS_PER_BATCH; ++k) {
+			hipLaunchKernelGGL(k_ploc_nn_d, dim3(nb), dim3(PB), 0, st, cbox[0], cbox[1], state, r, nn);
+			hipLaunchKernelGGL(k_ploc_count_d, dim3(nb), dim3(PB), 0, st, nn, state, flag, block_counts);
+			hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, st, block_counts, nb, totals, (const int*)state);
+			hipLaunchKernelGGL(k_ploc_merge_d, dim3(nb), dim3(PB), 0, st, cl[0], cl[1], cbox[0], cbox[1], nn, flag, block_counts, state, n,
+			                   left, right, node_parent, leaf_parent, slots);
+			hipLaunchKernelGGL(k_ploc_advance, dim3(1), dim3(1), 0, st, state, totals);
+		}
 		RT_HIP_CHECK(hipGetLastError());
-		RT_HIP_CHECK(hipMemcpyAsync(h_tot, totals, 8, hipMemcpyDeviceToHost, st));
+		RT_HIP_CHECK(hipMemcpyAsync(h_state, state, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
 		RT_HIP_CHECK(hipStreamSynchronize(st));
-		const int c_next = h_tot[0];
-		if (c_next > c || c_next < (c + 1) / 2) { rt_set_error("PLOC round produced %d clusters from %d", c_next, c); return RT_HIP_ERR_STATE; }
-		// no progress is only possible with exact distance ties; a forced round pairs neighbours
-		force = (c_next == c || ++rounds > 512) ? 1 : 0;
-		created += c - c_next;
-		c = c_next;
-		cur ^= 1;
+		if (h_state[PS_ERROR]) { rt_set_error("PLOC round produced %d clusters from at most %d", h_state[PS_ERROR] - 1, c); return RT_HIP_ERR_STATE; }
+		c = h_state[PS_C]; created = h_state[PS_CREATED]; cur = h_state[PS_CUR];
 	}
 	hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(PTAIL), 0, st, cl[cur], cbox[cur], c, r, n, created, left, right,
 	                   node_parent, leaf_parent, slots);
