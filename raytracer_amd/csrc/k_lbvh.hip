@@ -927,7 +927,7 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 // largest trace grid (rt_trace_blocks never launches more than max_trace_threads).
 int rt_reserve_spill(rt_hip_ctx* ctx)
 {
-	const int over = ctx->bvh_depth + 1 - ctx->tuning.lds_stack_depth;
+	const int over = ctx->bvh_depth + 2 - ctx->tuning.lds_stack_depth;  // = SceneView::stack_depth - lds depth
 	if (ctx->use_bvh && over > 0) RT_CHECK(ctx->d_spill.reserve((size_t)over * ctx->max_trace_threads * sizeof(int)));
 	return RT_HIP_OK;
 }

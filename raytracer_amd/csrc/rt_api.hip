@@ -94,6 +94,7 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->gather_fine = env_int("RT_HIP_GATHER_FINE", 1);
 	t->gather_xcd_chunk = env_int("RT_HIP_GATHER_XCD_CHUNK", 1024);
 	t->gather_fine_cells = env_int("RT_HIP_GATHER_FINE_CELLS", 8);
+	t->shadow_packet = env_int("RT_HIP_SHADOW_PACKET", 0);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
@@ -114,6 +115,7 @@ void rt_clamp_tuning(rt_hip_ctx* ctx)
 	t.gather_fine = t.gather_fine ? 1 : 0;
 	t.gather_xcd_chunk = std::min(8192, std::max(0, t.gather_xcd_chunk));
 	t.gather_fine_cells = std::min(32, std::max(2, t.gather_fine_cells));
+	t.shadow_packet = std::min(1 << 20, std::max(0, t.shadow_packet));
 	t.extra_lds_bytes = std::min(64 * 1024, std::max(0, t.extra_lds_bytes));
 	t.max_bvh_depth = std::min(95, std::max(1, t.max_bvh_depth));
 	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;
@@ -159,7 +161,7 @@ SceneView rt_scene_view(const rt_hip_ctx* ctx)
 	sv.num_materials = (int)ctx->materials.size() + sv.num_spheres;
 	sv.num_lights = (int)ctx->lights.size();
 	sv.use_bvh = ctx->use_bvh;
-	sv.stack_depth = ctx->bvh_depth + 1;
+	sv.stack_depth = ctx->bvh_depth + 2;  // + the EXIT sentinel at the bottom (bvh_trace)
 	sv.lds_depth = std::min(sv.stack_depth, ctx->tuning.lds_stack_depth);
 	sv.spill = ctx->d_spill.as<int>();
 	sv.spill_stride = ctx->max_trace_threads;
@@ -225,8 +227,8 @@ unsigned long long* rt_census_ptr(rt_hip_ctx* ctx, int cls)
 {
 	if (!ctx->cfg.census) return nullptr;
 	if (!ctx->d_census.p) {
-		if (ctx->d_census.reserve(64) != RT_HIP_OK) return nullptr;
-		if (hipMemset(ctx->d_census.p, 0, 64) != hipSuccess) return nullptr;  // synchronous: done before any kernel adds to it
+		if (ctx->d_census.reserve(128) != RT_HIP_OK) return nullptr;
+		if (hipMemset(ctx->d_census.p, 0, 128) != hipSuccess) return nullptr;  // synchronous: done before any kernel adds to it
 	}
 	return ctx->d_census.as<unsigned long long>() + (cls == 2 ? 6 : cls ? 3 : 0);
 }
@@ -247,8 +249,9 @@ int rt_collect_timing(rt_hip_ctx* ctx, size_t upto)
 	ctx->trace_events_collected = std::max(ctx->trace_events_collected, end);
 	if (ctx->trace_events_collected >= ctx->trace_events_used) ctx->trace_events_used = ctx->trace_events_collected = 0;
 	if (ctx->cfg.census && ctx->d_census.p) {
-		unsigned long long c[7];
+		unsigned long long c[12];
 		RT_HIP_CHECK(hipMemcpy(c, ctx->d_census.p, sizeof(c), hipMemcpyDeviceToHost));
+		for (int k = 0; k < 4; ++k) ctx->stats.packet_stats[k] = c[8 + k];
 		ctx->stats.census_nodes_closest = c[0]; ctx->stats.census_tris_closest = c[1]; ctx->stats.census_rays_closest = c[2];
 		ctx->stats.census_nodes_any = c[3]; ctx->stats.census_tris_any = c[4]; ctx->stats.census_rays_any = c[5];
 		ctx->stats.census_gather_visits = c[6];
@@ -434,6 +437,7 @@ int rt_hip_set_tuning(rt_hip_ctx* ctx, const rt_hip_tuning* tuning)
 {
 	RT_CHECK(check_ctx(ctx));
 	if (!tuning) { rt_set_error("null tuning"); return RT_HIP_ERR_ARG; }
+	if (ctx->pending_count > 0) { rt_set_error("%d frame(s) are enqueued: rt_hip_frame_finish() them before changing the tuning", ctx->pending_count); return RT_HIP_ERR_STATE; }
 	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	const rt_hip_tuning old = ctx->tuning;
 	ctx->tuning = *tuning;
@@ -444,8 +448,10 @@ int rt_hip_set_tuning(rt_hip_ctx* ctx, const rt_hip_tuning* tuning)
 		ctx->dirty_topology = true;
 		ctx->scene_dirty = true;
 	}
-	// the HBM part of the traversal stacks follows the LDS depth and the grid cap
-	if (!ctx->scene_dirty && ctx->use_bvh) RT_CHECK(rt_reserve_spill(ctx));
+	// The HBM part of the traversal stacks follows the LDS depth and the grid cap (max_trace_threads is both the grid cap
+	// and the stride of that array, and rt_clamp_tuning has just changed it): resize it now whenever a tree is in use, also
+	// when the scene is dirty for tables or matrices only -- those updates keep the tree (a pending rebuild sizes it itself).
+	if (ctx->use_bvh && !ctx->dirty_topology) RT_CHECK(rt_reserve_spill(ctx));
 	return RT_HIP_OK;
 }
 
@@ -595,8 +601,10 @@ int rt_hip_update(rt_hip_ctx* ctx)
 			rt_set_error("mesh material id %d outside the material table (%zu)", m.material, ctx->materials.size());
 			return RT_HIP_ERR_ARG;
 		}
+	if (ctx->pending_count > 0) { rt_set_error("%d frame(s) are enqueued: rt_hip_frame_finish() them before changing the scene", ctx->pending_count); return RT_HIP_ERR_STATE; }
 	if (!ctx->scene_dirty) { ctx->stats.last_update = RT_HIP_UPDATE_NONE; return RT_HIP_OK; }
 	RT_CHECK(rt_build_geometry(ctx));
+	if (ctx->use_bvh) RT_CHECK(rt_reserve_spill(ctx));  // every path (tables, refit, rebuild) leaves the overflow stacks sized for the tuning in force
 	ctx->scene_dirty = ctx->dirty_topology = ctx->dirty_tables = ctx->dirty_xf = false;
 	return RT_HIP_OK;
 }
@@ -956,16 +964,18 @@ int rt_hip_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
 	const uint8_t* d_img = host ? pf->fs.rgba[0] : nullptr;
 	const size_t bytes = host ? pf->img_bytes : 0;
 	if (pf) pf->host = false;
-	RT_CHECK(rt_frame_finish(ctx, out_rays));
+	const int status = rt_frame_finish(ctx, out_rays);
 	if (host) {
+		// also when the finish failed: the caller's buffer must not be written to after this call has returned
 		RT_HIP_CHECK(hipEventSynchronize(ev_down));
+		RT_CHECK(status);
 		if (ctx->frame_redone) {
 			// the frame was rendered again after the download had been queued (a level overflowed its bound): fetch it again
 			RT_HIP_CHECK(hipMemcpyAsync(h_rgba, d_img, bytes, hipMemcpyDeviceToHost, ctx->stream));
 			RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		}
 	}
-	return RT_HIP_OK;
+	return status;
 }
 
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx) { return ctx ? ctx->last_frame_rays : 0; }
@@ -1202,7 +1212,7 @@ int rt_hip_reset_stats(rt_hip_ctx* ctx)
 	ctx->stats.last_update = last_update;
 	ctx->stats.bvh_area_cost = ctx->use_bvh ? ctx->bvh_cost_now : 0.0;
 	ctx->stats.bvh_area_cost_built = ctx->use_bvh ? ctx->bvh_cost_built : 0.0;
-	if (ctx->d_census.p) RT_HIP_CHECK(hipMemset(ctx->d_census.p, 0, 64));
+	if (ctx->d_census.p) RT_HIP_CHECK(hipMemset(ctx->d_census.p, 0, 128));
 	ctx->stats.build_ms = build;
 	ctx->stats.num_tris = ctx->num_tris;
 	ctx->stats.num_nodes = ctx->num_nodes;

@@ -77,7 +77,7 @@ struct SceneView {
 	int num_materials;
 	int num_lights;
 	int use_bvh;      // 0: brute force over `tris`
-	int stack_depth;  // required traversal stack entries (BVH depth + 1)
+	int stack_depth;  // required traversal stack entries (BVH depth + 1, + 1 for the sentinel at the bottom)
 	int lds_depth;    // entries [0, lds_depth) of a lane's stack live in LDS, the rest in `spill`
 	int* spill;       // [stack_depth - lds_depth][spill_stride] ints in HBM (nullptr if not needed)
 	int spill_stride; // = maximum number of threads of a trace launch

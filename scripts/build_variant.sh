@@ -13,7 +13,7 @@ for s in rt_api.hip k_geometry.hip k_lbvh.hip k_sort.hip k_trace.hip k_frame.hip
   for v in "$@"; do
     if [ "$v" = "$s" ]; then
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-        -fno-gpu-rdc -Wall -Wno-unused-function $flags -c $s -o ../../variants_tmp/obj_$name/$o
+        -fno-gpu-rdc -Wall -Wno-unused-function $(make -s -f Makefile -p -n 2>/dev/null | sed -n "s/^FLAGS_${s%.hip} = //p") $flags -c $s -o ../../variants_tmp/obj_$name/$o
       o=../../variants_tmp/obj_$name/$o
     fi
   done

@@ -99,6 +99,8 @@ def test_host_pipeline_equals_host_frames():
     assert np.array_equal(d_out.cpu().numpy(), exp[3][0])
     # pageable memory works too (no overlap, same result)
     plain = np.full(w * h * 4, 9, np.uint8)
-    g.frame_enqueue_host(host[1][0].numpy().copy(), host[1][1].numpy().copy(), w, h, plain)
+    pos_copy, nrm_copy = host[1][0].numpy().copy(), host[1][1].numpy().copy()   # alive until frame_finish, as the contract asks
+    g.frame_enqueue_host(pos_copy, nrm_copy, w, h, plain)
     assert g.frame_finish() == exp[1][1] and np.array_equal(plain, exp[1][0])
+    del pos_copy, nrm_copy
     g.close()
