@@ -153,9 +153,7 @@ typedef struct rt_hip_tuning {
 	int gather_xcd_chunk;     /* 1024 RT_HIP_GATHER_XCD_CHUNK: consecutive queued shading points per XCD in the wave-per-point gather (their
 	                                 neighbourhoods overlap, so the XCD's L2 serves most of their photon reads); 0 = hardware order */
 	int gather_fine_cells;    /* 8    RT_HIP_GATHER_FINE_CELLS: fine photon grid cells per gather radius (2..32); read when a photon set is installed */
-	int shadow_packet;        /* 0  RT_HIP_SHADOW_PACKET: > 0 = the frame's shadow rays are walked by the wave (one traversal for the 64 rays of
-	                                 a wave, nodes through the scalar cache) for at most this many visits, then per lane; 0 = per lane only */
-	int reserved[2];
+	int reserved[3];
 } rt_hip_tuning;
 
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent
@@ -183,7 +181,6 @@ typedef struct rt_hip_stats {
 	uint64_t census_gather_visits; /* census: photons in the grid cells the points' mandatory first pass reads */
 	double bvh_area_cost;       /* sum of the BVH nodes' surface areas / the root's: the tree in use (after a refit: the refitted boxes) */
 	double bvh_area_cost_built; /* the same when the topology was built; a refit is kept while cost <= tuning.refit_max_growth x this */
-	uint64_t packet_stats[4];   /* census + RT_HIP_PACKET_STATS: wave packets walked, their node + leaf visits, their leaf visits, rays handed to the per-lane traversal */
 } rt_hip_stats;
 
 /* ---- life cycle --------------------------------------------------------------------------- */

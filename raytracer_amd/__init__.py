@@ -54,15 +54,14 @@ class Stats(C.Structure):
                 ("census_rays_closest", C.c_uint64), ("census_nodes_any", C.c_uint64),
                 ("census_tris_any", C.c_uint64), ("census_rays_any", C.c_uint64),
                 ("gather_ms", C.c_double), ("gather_launches", C.c_int64), ("gather_points", C.c_int64),
-                ("census_gather_visits", C.c_uint64), ("bvh_area_cost", C.c_double), ("bvh_area_cost_built", C.c_double),
-                ("packet_stats", C.c_uint64 * 4)]
+                ("census_gather_visits", C.c_uint64), ("bvh_area_cost", C.c_double), ("bvh_area_cost_built", C.c_double)]
 
 
 class Tuning(C.Structure):
     """rt_hip_tuning (include/rt_hip.h): knobs outside the reference's semantics."""
     _fields_ = [("lds_stack_depth", C.c_int), ("xcd_chunk", C.c_int), ("trace_oversub", C.c_int), ("auto_accel", C.c_int),
                 ("ploc_radius", C.c_int), ("frame_sync", C.c_int), ("gather_heavy", C.c_uint32), ("extra_lds_bytes", C.c_int),
-                ("max_bvh_depth", C.c_int), ("refit_max_growth", C.c_float), ("gather_fine", C.c_int), ("gather_xcd_chunk", C.c_int), ("gather_fine_cells", C.c_int), ("shadow_packet", C.c_int), ("reserved", C.c_int * 2)]
+                ("max_bvh_depth", C.c_int), ("refit_max_growth", C.c_float), ("gather_fine", C.c_int), ("gather_xcd_chunk", C.c_int), ("gather_fine_cells", C.c_int), ("reserved", C.c_int * 3)]
 
 
 UPDATE_NONE, UPDATE_TABLES, UPDATE_REFIT, UPDATE_REBUILD = 0, 1, 2, 3

@@ -623,71 +623,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 	if (CENSUS && census) census_add(census, cn, ct, rays);
 }
 
-// The same launch with the shadow rays walked by the WAVE (packet_any, rt_trace_dev.h): one wave per workgroup,
-// 64 consecutive (light, node) items per round, the per-lane traversal only for what the packet walk gives up
-// on.  pstats (census runs only): [0] packets, [1] node + leaf visits of the packet walks, [2] leaf visits,
-// [3] rays handed to the per-lane traversal.
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow_packet(SceneView sv, const NodeGeo* __restrict__ geo, int n,
-                                                        const int* __restrict__ n_ptr, int light_lo, int light_hi,
-                                                        float shadow_t_max, unsigned int* __restrict__ occl,
-                                                        int budget, unsigned long long* pstats, FusedQueue fq)
-{
-	n = dev_count(n, n_ptr);
-	extern __shared__ __attribute__((aligned(16))) int smem[];
-	lds_int* stack = RT_LDS_STACK(smem) + threadIdx.x;
-	if (fq.org) {
-		const int nq = dev_count(fq.capacity, fq.count_ptr);
-		grid_for_each(sv, nq, [&](int64_t i) {
-			f3 O = ld3(fq.org + 3 * (size_t)i), D = ld3(fq.dir + 3 * (size_t)i);
-			Hit best;
-			uint32_t a = 0, b = 0;
-			bvh_trace<false, false>(sv, O, D, best, stack, TRACE_BLOCK, a, b);
-			fq.hits[i] = best;
-		});
-	}
-	if (shadow_t_max > 0.0f) sv.tp.t_max = shadow_t_max;
-	const int64_t total = (int64_t)n * (light_hi - light_lo);
-	const int64_t gsize = (int64_t)gridDim.x * TRACE_BLOCK;
-	PacketStats ps = {0u, 0u, 0u};
-	uint32_t packets = 0;
-	// wave-uniform loop: the whole wave takes every round, lanes past the end carry no ray
-	for (int64_t base = xcd_block_index(sv.xcd_chunk) * TRACE_BLOCK; base < total; base += gsize) {
-		const int64_t idx = base + threadIdx.x;
-		bool want = idx < total;
-		int light = light_lo, i = 0;
-		f3 O = mk3(0, 0, 0), L = mk3(0, 0, 1);
-		if (want) {
-			light = light_lo + (int)(idx / n); i = (int)(idx % n);
-			const NodeGeo g = geo[i];
-			want = g.material >= 0;
-			const f3 V = ld3(g.V), N = ld3(g.N);
-			L = ld3(sv.lights[light].position) - V;
-			O = V + N * 0.1f;  // bias = 0.1 (rt_raytracer.cpp:79,112)
-		}
-		bool unresolved;
-		bool blocked = packet_any(sv, O, L, want, budget, unresolved, pstats ? &ps : nullptr);
-		++packets;
-		if (unresolved) {
-			Hit best;
-			uint32_t a = 0, b = 0;
-			blocked = bvh_trace<true, false>(sv, O, L, best, stack, TRACE_BLOCK, a, b);
-			++ps.fallback;
-		}
-		// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116)
-		if (want && blocked && 0.0f < norm3(L)) atomicOr(&occl[i], 1u << light);
-	}
-	if (pstats) {
-		uint32_t fb = ps.fallback;
-		for (int off = 32; off >= 1; off >>= 1) fb += __shfl_xor(fb, off);
-		if (threadIdx.x == 0) {
-			atomicAdd(&pstats[0], (unsigned long long)packets);
-			atomicAdd(&pstats[1], (unsigned long long)ps.visits);
-			atomicAdd(&pstats[2], (unsigned long long)ps.leaves);
-			atomicAdd(&pstats[3], (unsigned long long)fb);
-		}
-	}
-}
-
 // light_color() without a photon map (rt_raytracer.cpp:98-123): lambert accumulated and clamped
 // light by light, -0.4 per occluded light (Q8).
 __device__ __forceinline__ float light_factor(const SceneView& sv, f3 V, f3 N, unsigned int oc)
@@ -1452,11 +1387,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		// timed (profile mode) through the dispatch itself: no event markers between the frame's kernels
 		hipEvent_t t0, t1;
 		RT_CHECK(rt_next_trace_events(ctx, 1, &t0, &t1));
-		static const bool packet_stats = getenv("RT_HIP_PACKET_STATS") != nullptr;  // census runs: statistics of the packet walk instead of the per-ray census
-		if (ctx->tuning.shadow_packet > 0 && sv.use_bvh && sv.num_tris > 0 && hi > lo && (!cen || packet_stats))
-			hipExtLaunchKernelGGL(k_shadow_packet, dim3(blocks), dim3(TRACE_BLOCK), (uint32_t)lds, st, t0, t1, 0u, sv, geo, n, n_ptr, lo, hi,
-			                      ctx->cfg.shadow_t_max, occl, ctx->tuning.shadow_packet, cen ? cen + 5 : cen, fq);
-		else if (cen)
+		if (cen)
 			hipExtLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(TRACE_BLOCK), (uint32_t)lds, st, t0, t1, 0u, sv, geo, n, n_ptr, lo, hi,
 			                      ctx->cfg.shadow_t_max, occl, cen, fq);
 		else

@@ -94,7 +94,6 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->gather_fine = env_int("RT_HIP_GATHER_FINE", 1);
 	t->gather_xcd_chunk = env_int("RT_HIP_GATHER_XCD_CHUNK", 1024);
 	t->gather_fine_cells = env_int("RT_HIP_GATHER_FINE_CELLS", 8);
-	t->shadow_packet = env_int("RT_HIP_SHADOW_PACKET", 0);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
@@ -115,7 +114,6 @@ void rt_clamp_tuning(rt_hip_ctx* ctx)
 	t.gather_fine = t.gather_fine ? 1 : 0;
 	t.gather_xcd_chunk = std::min(8192, std::max(0, t.gather_xcd_chunk));
 	t.gather_fine_cells = std::min(32, std::max(2, t.gather_fine_cells));
-	t.shadow_packet = std::min(1 << 20, std::max(0, t.shadow_packet));
 	t.extra_lds_bytes = std::min(64 * 1024, std::max(0, t.extra_lds_bytes));
 	t.max_bvh_depth = std::min(95, std::max(1, t.max_bvh_depth));
 	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;
@@ -249,9 +247,8 @@ int rt_collect_timing(rt_hip_ctx* ctx, size_t upto)
 	ctx->trace_events_collected = std::max(ctx->trace_events_collected, end);
 	if (ctx->trace_events_collected >= ctx->trace_events_used) ctx->trace_events_used = ctx->trace_events_collected = 0;
 	if (ctx->cfg.census && ctx->d_census.p) {
-		unsigned long long c[12];
+		unsigned long long c[7];
 		RT_HIP_CHECK(hipMemcpy(c, ctx->d_census.p, sizeof(c), hipMemcpyDeviceToHost));
-		for (int k = 0; k < 4; ++k) ctx->stats.packet_stats[k] = c[8 + k];
 		ctx->stats.census_nodes_closest = c[0]; ctx->stats.census_tris_closest = c[1]; ctx->stats.census_rays_closest = c[2];
 		ctx->stats.census_nodes_any = c[3]; ctx->stats.census_tris_any = c[4]; ctx->stats.census_rays_any = c[5];
 		ctx->stats.census_gather_visits = c[6];

@@ -133,115 +133,6 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 	return found;
 }
 
-// ---- wave-packet any-hit traversal -------------------------------------------------------------------
-// The 64 shadow rays of a wave share their light and start on neighbouring texels (level 0: one 8x8 tile), so
-// they cross almost the same boxes.  Here the WAVE walks the tree once for all of them: the current node is
-// wave-uniform, arrives through the scalar cache (s_load of the float node: no vector-memory instruction, no
-// TA/TD work) and feeds the slab test as SGPR operands; every lane tests its own ray; the compare results ARE
-// the ballots that say which child any live lane needs; the stack is the wave's, in one VGPR (entry k in lane
-// k, v_writelane / v_readlane) -- no LDS, no exec-mask bookkeeping: every branch of the loop is scalar.  A leaf's
-// triangle comes through the scalar cache too and is tested by all live lanes; lanes that found an occluder
-// leave `alive`.  The boolean per ray is that of bvh_trace<true>: any-hit does not depend on the order of the
-// visits, the box test only culls, and the triangle test is mt_any on the same operands.
-// An incoherent wave (rays of two lights, a silhouette, deep reflections) would drag all 64 lanes through the
-// union of 64 different paths, so the walk has a budget: past `budget` visits, or past 64 stack entries, the
-// lanes still alive are returned as `unresolved` and the caller traces them per lane, from the root.
-typedef float v16f __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(4))) const v16f cs_node;  // one BvhNode: 12 plane coordinates, left, right, parent, pad
-typedef __attribute__((address_space(4))) const v4f cs_vec4;
-
-struct PacketStats { uint32_t visits, leaves, fallback; };
-
-// Slab test of one ray against a wave-uniform float box: t = plane * inv + b with b = -o * inv.  The roundings are
-// covered by one per-ray delta (the largest of the three axes' bounds, each as in ray_pre), applied to the
-// interval's ends.
-struct RayPreF {
-	float ix, iy, iz, bx, by, bz, delta;
-};
-__device__ __forceinline__ RayPreF ray_pre_f(const QFrame& qf, f3 o, f3 d)
-{
-	RayPreF r;
-	r.ix = safe_rcp(d.x); r.iy = safe_rcp(d.y); r.iz = safe_rcp(d.z);
-	r.bx = -o.x * r.ix; r.by = -o.y * r.iy; r.bz = -o.z * r.iz;
-	const float eps = 4.76837158203125e-07f;  // 2^-21
-	const float ex = __builtin_fmaf(fabsf(r.ix), qf.reach[0] + fabsf(o.x), fabsf(r.bx));
-	const float ey = __builtin_fmaf(fabsf(r.iy), qf.reach[1] + fabsf(o.y), fabsf(r.by));
-	const float ez = __builtin_fmaf(fabsf(r.iz), qf.reach[2] + fabsf(o.z), fabsf(r.bz));
-	r.delta = fmaxf(fmaxf(ex, ey), ez) * eps;
-	return r;
-}
-__device__ __forceinline__ bool slab_f(const RayPreF& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
-                                       float tlimit)
-{
-	const float x0 = __builtin_fmaf(mnx, r.ix, r.bx), x1 = __builtin_fmaf(mxx, r.ix, r.bx);
-	const float y0 = __builtin_fmaf(mny, r.iy, r.by), y1 = __builtin_fmaf(mxy, r.iy, r.by);
-	const float z0 = __builtin_fmaf(mnz, r.iz, r.bz), z1 = __builtin_fmaf(mxz, r.iz, r.bz);
-	const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1)) - r.delta;
-	const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) + r.delta;
-	return fmaxf(tn, 0.0f) <= fminf(tf, tlimit);
-}
-
-// Every lane of the wave calls this together (converged); `want`: this lane carries a ray.  Returns blocked?;
-// `unresolved`: the ray was neither blocked nor finished when the walk gave up.
-__device__ __forceinline__ bool packet_any(const SceneView& sv, f3 O, f3 D, bool want, int budget, bool& unresolved,
-                                           PacketStats* ps)
-{
-	unresolved = false;
-	uint64_t alive = __ballot(want);
-	if (alive == 0 || sv.num_tris <= 0) return false;
-	cs_node* nodes = (cs_node*)sv.nodes;
-	cs_vec4* tris = (cs_vec4*)sv.tris;
-	const RayPreF rp = ray_pre_f(sv.qframe, O, D);
-	const float tlimit = sv.tp.t_max;
-	bool blocked = false;
-	int stackv = 0;  // the wave's stack: entry k lives in lane k
-	int sp = 0;
-	int cur = (sv.num_tris == 1) ? ~0 : 0;
-	int visits = 0;
-	for (;;) {
-		bool pop;
-		if (cur >= 0) {
-			const v16f nd = nodes[cur];
-			const int lc = (int)__float_as_uint(nd[12]), rc = (int)__float_as_uint(nd[13]);
-			const bool hl = slab_f(rp, nd[0], nd[1], nd[2], nd[3], nd[4], nd[5], tlimit);
-			const bool hr = slab_f(rp, nd[6], nd[7], nd[8], nd[9], nd[10], nd[11], tlimit);
-			const uint64_t ml = __ballot(hl) & alive, mr = __ballot(hr) & alive;
-			if (ml && mr) {
-				// the child more of the live rays need first; the other one waits on the stack
-				const bool left_first = __popcll(ml) >= __popcll(mr);
-				if (sp >= 64) break;
-				stackv = (lane_id() == sp) ? (left_first ? rc : lc) : stackv;
-				++sp;
-				cur = left_first ? lc : rc;
-				pop = false;
-			} else {
-				cur = ml ? lc : rc;
-				pop = !(ml | mr);
-			}
-		} else {
-			cs_vec4* tp = tris + 3 * (size_t)(~cur);
-			const v4f a = tp[0], b = tp[1], c = tp[2];
-			if (ps) ++ps->leaves;
-			const bool hit = mt_any(O, D, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), mk3(c.x, c.y, c.z), sv.tp);
-			const uint64_t mh = __ballot(hit) & alive;
-			if ((alive >> lane_id()) & 1ull) blocked = blocked || hit;
-			alive &= ~mh;
-			if (alive == 0) break;
-			pop = true;
-		}
-		if (pop) {
-			if (sp == 0) { alive = 0; break; }
-			--sp;
-			cur = __builtin_amdgcn_readlane(stackv, sp);
-		}
-		if (++visits >= budget) break;
-	}
-	if (ps) ps->visits += (uint32_t)visits;
-	unresolved = ((alive >> lane_id()) & 1ull) != 0;
-	return blocked;
-}
-
 // Census mode: wave-reduce the per-ray counters, one 64-bit atomic triple per wave.
 __device__ __forceinline__ void census_add(unsigned long long* census, uint32_t nodes, uint32_t tris, uint32_t rays)
 {
