@@ -435,6 +435,11 @@ __device__ __forceinline__ uint32_t quant_hi(float v, float org, float scale)
 	return (uint32_t)q;
 }
 
+__device__ __forceinline__ uint32_t qnode_ref(int child)
+{
+	return child >= 0 ? (uint32_t)child * (uint32_t)sizeof(QNode) : ~((uint32_t)(~child) * (uint32_t)sizeof(TriIsect));
+}
+
 // list == nullptr: every internal node, boxes already in `slots` (the builders that make boxes as they go).
 // list != nullptr: the `count` nodes of one tree level; each also writes its own box = the union of its children's
 // (the level-by-level refit), so that the next launch, one level up, finds it.
@@ -462,7 +467,8 @@ __device__ __forceinline__ void emit_node(BoxSlot* __restrict__ slots, int n, in
 	}
 	QNode qn;
 	qn.w0 = make_uint4(lq[0] | lq[3] << 16, lq[1] | lq[4] << 16, lq[2] | lq[5] << 16, rq[0] | rq[3] << 16);
-	qn.w1 = make_uint4(rq[1] | rq[4] << 16, rq[2] | rq[5] << 16, (uint32_t)lc, (uint32_t)rc);
+	// child references as the traversal uses them: byte offset of the child's QNode (>= 0), or ~(byte offset of the leaf's TriIsect)
+	qn.w1 = make_uint4(rq[1] | rq[4] << 16, rq[2] | rq[5] << 16, qnode_ref(lc), qnode_ref(rc));
 	qnodes[i] = qn;
 }
 
@@ -830,6 +836,7 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 	hipStream_t st = ctx->stream;
 	const int n = ctx->num_tris;
 	const int g = (n + 255) / 256;
+	if (n > RT_MAX_BVH_TRIS) { rt_set_error("%d triangles: the BVH takes at most %d (32-bit child references)", n, RT_MAX_BVH_TRIS); return RT_HIP_ERR_LIMIT; }
 	RT_CHECK(ctx->d_morton.reserve((size_t)n * 8));
 	RT_CHECK(ctx->d_morton_tmp.reserve((size_t)n * 8));
 	RT_CHECK(ctx->d_order.reserve((size_t)n * 4));

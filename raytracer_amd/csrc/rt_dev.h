@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #define RT_MISS 0xFFFFFFFFu
+#define RT_MAX_BVH_TRIS (1 << 25)  // 32-bit child references: 2^25 x 48-byte leaves and 2^25 x 32-byte nodes stay below 2^31
 #define RT_WAVE 64
 
 struct f3 {
@@ -61,7 +62,10 @@ static_assert(sizeof(BvhNode) == 64, "BVH node is one 64-byte line");
 // nodes (BvhNode) remain the build's output and what rt_hip_get_bvh returns.
 // A plane pair (min | max << 16) per axis and child, so that one rotate by 0 or 16 bits puts the plane
 // the ray enters through in the low half-word:
-//   w0 = (l.x, l.y, l.z, r.x)   w1 = (r.y, r.z, bits left, bits right)      with  c.k = c.min.k | c.max.k << 16
+//   w0 = (l.x, l.y, l.z, r.x)   w1 = (r.y, r.z, ref left, ref right)        with  c.k = c.min.k | c.max.k << 16
+// A child reference is what the traversal adds to a base pointer: the byte offset of the child's QNode (>= 0), or
+// ~(byte offset of the leaf's TriIsect) (< 0), so that a fetch needs no address arithmetic beyond the load's own
+// scalar-base + 32-bit-offset form.  Offsets stay below 0x7ffffffc (the traversal's sentinels): RT_MAX_BVH_TRIS.
 struct __attribute__((aligned(32))) QNode {
 	uint4 w0, w1;
 };

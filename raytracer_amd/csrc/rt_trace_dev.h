@@ -20,20 +20,22 @@ typedef __attribute__((address_space(3))) int lds_int;
 // through the loop as a pointer: held to 64 VGPRs, k_shadow otherwise spills that pointer to scratch at entry.
 __device__ __forceinline__ size_t spill_column(int stride) { return (size_t)blockIdx.x * (size_t)stride + threadIdx.x; }
 
+// The stack pointer is the LDS address of the next free entry (`top`, advancing by `stride` ints), `lim` the first
+// address past the lane's LDS part: push and pop are one LDS instruction at an address that is already in a register.
 // The overflow part is reached through a WAVE-uniform test (no lane of the wave is that deep: the common case by far),
-// so that the usual push / pop is one LDS instruction under the caller's mask with no second level of exec handling.
-__device__ __forceinline__ void stack_push(const SceneView& sv, lds_int* stack, int stride, int sp, int v)
+// so that the usual push / pop has no second level of exec handling.
+__device__ __forceinline__ void stack_push(const SceneView& sv, lds_int* top, lds_int* lim, int stride, int v)
 {
-	if (__builtin_amdgcn_ballot_w64(sp >= sv.lds_depth) == 0) { stack[sp * stride] = v; return; }
-	if (sp < sv.lds_depth) stack[sp * stride] = v;
-	else sv.spill[(size_t)(sp - sv.lds_depth) * sv.spill_stride + spill_column(stride)] = v;
+	if (__builtin_amdgcn_ballot_w64(top >= lim) == 0) { *top = v; return; }
+	if (top < lim) *top = v;
+	else sv.spill[(size_t)((int)(top - lim) / stride) * sv.spill_stride + spill_column(stride)] = v;
 }
-__device__ __forceinline__ int stack_pop(const SceneView& sv, const lds_int* stack, int stride, int sp)
+__device__ __forceinline__ int stack_pop(const SceneView& sv, const lds_int* top, const lds_int* lim, int stride)
 {
-	if (__builtin_amdgcn_ballot_w64(sp >= sv.lds_depth) == 0) return stack[sp * stride];
+	if (__builtin_amdgcn_ballot_w64(top >= lim) == 0) return *top;
 	int v;
-	if (sp < sv.lds_depth) v = stack[sp * stride];
-	else v = sv.spill[(size_t)(sp - sv.lds_depth) * sv.spill_stride + spill_column(stride)];
+	if (top < lim) v = *top;
+	else v = sv.spill[(size_t)((int)(top - lim) / stride) * sv.spill_stride + spill_column(stride)];
 	return v;
 }
 
@@ -90,11 +92,13 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 		// empty-stack test.
 		const int EXIT = 0x7fffffff, HIT = 0x7ffffffe, POP = 0x7ffffffd;
 		int cur = (sv.num_tris == 1) ? ~0 : 0;
-		stack_push(sv, stack, stride, 0, EXIT);
-		int sp = 1;
+		lds_int* const lim = stack + sv.lds_depth * stride;
+		stack_push(sv, stack, lim, stride, EXIT);
+		lds_int* top = stack + stride;
 		while (cur < POP) {
 			if (cur >= 0) {
-				const uint4* np = (const uint4*)(sv.qnodes + cur);
+				// cur = byte offset of the node (k_lbvh.hip: qnode_ref)
+				const uint4* np = (const uint4*)((const char*)sv.qnodes + (uint32_t)cur);
 				const uint4 w0 = np[0], w1 = np[1];
 				const int2 ch = make_int2((int)w1.z, (int)w1.w);
 				if (CENSUS) ++cnt_nodes;
@@ -106,12 +110,12 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 				const float inf = __builtin_inff();
 				const bool right_first = (hr ? tr : inf) < (hl ? tl : inf);
 				if (hl && hr) {
-					stack_push(sv, stack, stride, sp, right_first ? ch.x : ch.y);
-					++sp;
+					stack_push(sv, top, lim, stride, right_first ? ch.x : ch.y);
+					top += stride;
 				}
 				cur = (hl || hr) ? (right_first ? ch.y : ch.x) : POP;
 			} else {
-				const TriIsect* tp = sv.tris + (~cur);
+				const TriIsect* tp = (const TriIsect*)((const char*)sv.tris + (uint32_t)(~cur));
 				float4 a = tp->a, b = tp->b, c = tp->c;
 				// keep the three loads together: left alone, the compiler sinks the load of `a` below
 				// the det test and the leaf visit pays two memory round trips instead of one
@@ -125,7 +129,7 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 					cur = POP;
 				}
 			}
-			if (cur == POP) { --sp; cur = stack_pop(sv, stack, stride, sp); }
+			if (cur == POP) { top -= stride; cur = stack_pop(sv, top, lim, stride); }
 		}
 		found = ANY ? (cur == HIT) : (best.prim != RT_MISS);
 	}
