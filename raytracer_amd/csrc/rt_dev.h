@@ -200,23 +200,22 @@ __device__ __forceinline__ bool mt_occlude_ref(f3 O, f3 D, f3 v0, f3 e1, f3 e2, 
 
 // ---- conservative ray/box (slab) test ------------------------------------------------------
 // Not the reference's Woo test (rt_raytracer.cpp:194-248, which ignores ray.t and only culls):
-// a slab test on boxes that were padded at build time.  (b - o) * inv carries <= 2 ulp of
-// relative error, so the interval is widened by 4 ulp on each side and the test never rejects a
-// box whose triangle the exact M-T test would accept.
+// a slab test on boxes that were padded at build time and rounded outward onto a 16-bit grid.  The
+// roundings of the test itself are bounded per ray and folded into its additive constants (ray_pre),
+// so it never rejects a box whose triangle the exact M-T test would accept; there is no
+// multiplicative widening of the interval.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Ray constants for the slab test against quantised planes: t = q * a + b with a = scale / d and
-// b = (org - o) / d, one packed-FP32 FMA per (min, max) plane pair, 6 per node visit.  The one rounding
-// of the FMA against terms of magnitude |org - o| / |d| displaces a plane by at most ~1e-7 of the scene
-// extent, which the 1e-5-extent padding of the boxes at build time covers (as does the outward rounding
-// of the 16-bit grid); |d| < 1e-20 is replaced by +-1e-20 before inversion (no inf, no 0 * inf NaN).
-// rot = 16 where d < 0: the pair is rotated before unpacking so that its low half is the entry plane.
-// fma(q, a, b) is monotone in q, so for a > 0 the min plane's t is the smaller one (and the larger for
-// a < 0): choosing by the sign of d gives exactly min / max of the two, without computing them.
+// b = (org - o) / d, one packed-FP32 FMA per (entry, exit) plane pair, 6 per node visit.  |d| < 1e-20 is replaced by
+// +-1e-20 before inversion (no inf, no 0 * inf NaN).  fma(q, a, b) is monotone in q, so for a > 0 the min plane's t is
+// the smaller one (and the larger for a < 0): choosing the entry plane by the sign of d gives exactly min / max of the
+// two, without computing them.
 struct RayPre {
 	float ax, ay, az;
-	v2f bx, by, bz;     // (b - delta, b + delta): entry planes a little earlier, exit planes a little later
-	uint32_t rx, ry, rz;
+	v2f bx, by, bz;        // (B_entry, B_exit), see ray_pre
+	uint32_t ex, ey, ez;   // v_perm selectors: the entry plane's 16 bits under the exponent of 2^23
+	uint32_t xx, xy, xz;   // ... the exit plane's
 };
 
 __device__ __forceinline__ float safe_rcp(float d)
@@ -227,6 +226,16 @@ __device__ __forceinline__ float safe_rcp(float d)
 
 __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 
+// The 16-bit plane index q never goes through an integer-to-float conversion: v_perm_b32 drops its two bytes under the
+// bit pattern of 2^23 (0x4B000000), which reads as the float m = 2^23 + q exactly, and t = fma(m, a, B) with
+// B = b - 2^23 * a.  One v_perm per plane (12 per node visit) instead of a rotate per pair and a convert per plane
+// (6 + 12).  The price is the rounding of B, whose magnitude is that of 2^23 * a: up to one grid step |a| in t, so the
+// entry planes are taken one step earlier and the exit planes one step later (B -+ |a|), i.e. every box one grid cell
+// (extent / 65535) larger on each side than stored -- the test only culls, so results cannot change, and a cell is
+// ~1 % of a leaf box of the bench scenes.  delta (the rounding bound of ray_pre's b, see there) enters twice, once for b
+// and once for B's own rounding when |b| dominates 2^23 |a| (origins more than ~128 scene extents away).
+// Which half of the stored (min | max << 16) pair is the entry plane depends on the sign of the direction: that choice
+// is in the selectors.
 __device__ __forceinline__ RayPre ray_pre(const QFrame& qf, f3 o, f3 d)
 {
 	RayPre r;
@@ -240,17 +249,26 @@ __device__ __forceinline__ RayPre ray_pre(const QFrame& qf, f3 o, f3 d)
 	const float ex = __builtin_fmaf(fabsf(ix), qf.reach[0] + fabsf(o.x), fabsf(bx)) * eps;
 	const float ey = __builtin_fmaf(fabsf(iy), qf.reach[1] + fabsf(o.y), fabsf(by)) * eps;
 	const float ez = __builtin_fmaf(fabsf(iz), qf.reach[2] + fabsf(o.z), fabsf(bz)) * eps;
-	r.bx = mk2(bx - ex, bx + ex); r.by = mk2(by - ey, by + ey); r.bz = mk2(bz - ez, bz + ez);
-	r.rx = (__float_as_uint(ix) >> 31) << 4; r.ry = (__float_as_uint(iy) >> 31) << 4; r.rz = (__float_as_uint(iz) >> 31) << 4;
+	const float two23 = 8388608.0f;
+	r.bx = mk2(__builtin_fmaf(-two23, r.ax, bx - 2.0f * ex) - fabsf(r.ax), __builtin_fmaf(-two23, r.ax, bx + 2.0f * ex) + fabsf(r.ax));
+	r.by = mk2(__builtin_fmaf(-two23, r.ay, by - 2.0f * ey) - fabsf(r.ay), __builtin_fmaf(-two23, r.ay, by + 2.0f * ey) + fabsf(r.ay));
+	r.bz = mk2(__builtin_fmaf(-two23, r.az, bz - 2.0f * ez) - fabsf(r.az), __builtin_fmaf(-two23, r.az, bz + 2.0f * ez) + fabsf(r.az));
+	// selector bytes: 0-3 = bytes of the plane pair, 0x0c = 0x00, 7 = the top byte of 0x4B000000
+	const uint32_t lo = 0x070c0100u, hi = 0x070c0302u;
+	const bool nx = (__float_as_uint(ix) >> 31) != 0, ny = (__float_as_uint(iy) >> 31) != 0, nz = (__float_as_uint(iz) >> 31) != 0;
+	r.ex = nx ? hi : lo; r.xx = nx ? lo : hi;
+	r.ey = ny ? hi : lo; r.xy = ny ? lo : hi;
+	r.ez = nz ? hi : lo; r.xz = nz ? lo : hi;
 	return r;
 }
 
-__device__ __forceinline__ v2f unpack16(uint32_t w) { return mk2((float)(w & 0xffffu), (float)(w >> 16)); }
 __device__ __forceinline__ v2f fma2(v2f q, v2f a, v2f b) { return __builtin_elementwise_fma(q, a, b); }
-// (t at the entry plane, t at the exit plane) of one axis
-__device__ __forceinline__ v2f slab_axis(uint32_t w, uint32_t rot, float a, v2f b)
+// (t at the entry plane, t at the exit plane) of one axis; w = min | max << 16
+__device__ __forceinline__ v2f slab_axis(uint32_t w, uint32_t sel_entry, uint32_t sel_exit, float a, v2f b)
 {
-	return fma2(unpack16(__builtin_amdgcn_alignbit(w, w, rot)), mk2(a, a), b);
+	const uint32_t k = 0x4B000000u;
+	const v2f m = mk2(__uint_as_float(__builtin_amdgcn_perm(k, w, sel_entry)), __uint_as_float(__builtin_amdgcn_perm(k, w, sel_exit)));
+	return fma2(m, mk2(a, a), b);
 }
 
 // Both child boxes of a node against one ray.  Hit iff the slab interval intersects [0, tlimit]; entry
@@ -258,14 +276,14 @@ __device__ __forceinline__ v2f slab_axis(uint32_t w, uint32_t rot, float a, v2f 
 __device__ __forceinline__ void slab2(const RayPre& r, uint4 w0, uint4 w1, float tlimit, bool& hl, bool& hr,
                                       float& tl, float& tr)
 {
-	const v2f lx = slab_axis(w0.x, r.rx, r.ax, r.bx), ly = slab_axis(w0.y, r.ry, r.ay, r.by), lz = slab_axis(w0.z, r.rz, r.az, r.bz);
-	const v2f qx = slab_axis(w0.w, r.rx, r.ax, r.bx), qy = slab_axis(w1.x, r.ry, r.ay, r.by), qz = slab_axis(w1.y, r.rz, r.az, r.bz);
+	const v2f lx = slab_axis(w0.x, r.ex, r.xx, r.ax, r.bx), ly = slab_axis(w0.y, r.ey, r.xy, r.ay, r.by), lz = slab_axis(w0.z, r.ez, r.xz, r.az, r.bz);
+	const v2f qx = slab_axis(w0.w, r.ex, r.xx, r.ax, r.bx), qy = slab_axis(w1.x, r.ey, r.xy, r.ay, r.by), qz = slab_axis(w1.y, r.ez, r.xz, r.az, r.bz);
 	const float tnl = fmaxf(fmaxf(lx.x, ly.x), fmaxf(lz.x, 0.0f));
 	const float tfl = fminf(fminf(lx.y, ly.y), lz.y);
 	const float tnr = fmaxf(fmaxf(qx.x, qy.x), fmaxf(qz.x, 0.0f));
 	const float tfr = fminf(fminf(qx.y, qy.y), qz.y);
-	// No multiplicative widening of [tn, tf] here: the rounding of t = fma(q, a, b) is covered by the delta
-	// folded into b (ray_pre), on top of the build-time pad of 1e-5 x extent and the outward rounding of the grid.
+	// No multiplicative widening of [tn, tf] here: the roundings of t are covered by what ray_pre folded into B,
+	// on top of the build-time pad of 1e-5 x extent and the outward rounding of the grid.
 	tl = tnl; tr = tnr;
 	hl = tnl <= fminf(tfl, tlimit);
 	hr = tnr <= fminf(tfr, tlimit);
