@@ -153,7 +153,10 @@ typedef struct rt_hip_tuning {
 	int gather_xcd_chunk;     /* 1024 RT_HIP_GATHER_XCD_CHUNK: consecutive queued shading points per XCD in the wave-per-point gather (their
 	                                 neighbourhoods overlap, so the XCD's L2 serves most of their photon reads); 0 = hardware order */
 	int gather_fine_cells;    /* 8    RT_HIP_GATHER_FINE_CELLS: fine photon grid cells per gather radius (2..32); read when a photon set is installed */
-	int reserved[3];
+	uint32_t gather_medium;   /* 4096 RT_HIP_GATHER_MEDIUM: first pass of the wave-per-point gather: a point whose coarse cube holds at most this many
+	                                 photons reads them all from the coarse grid; above it the fine grid's cells inside the sphere are counted from
+	                                 the cell table and only the boundary shell is read; 0 = always the shell walk */
+	int reserved[2];
 } rt_hip_tuning;
 
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent

@@ -305,15 +305,7 @@ __device__ __forceinline__ uint32_t wave_sum_u(uint32_t v)
 // their lengths across the lanes, then element e of the concatenation belongs to the run found by a 6-step binary
 // search over the lanes' prefix sums (shuffles) -- and read 256 elements per round, whatever run they belong to.
 // visit(q, slot, active) runs in wave-uniform control flow.
-#ifndef RT_GATHER_LONG
 #define RT_GATHER_LONG 256u
-#endif
-#ifdef RT_GATHER_PROBE   // probe builds: what the calls of wave_visit_runs are made of (scripts/gather_sweep.py prints it)
-__device__ unsigned long long g_gather_probe[16];
-#define RT_PROBE_ADD(i, v) do { const unsigned long long v__ = (unsigned long long)(v); if (lane_id() == 0) atomicAdd(&g_gather_probe[i], v__); } while (0)
-#else
-#define RT_PROBE_ADD(i, v) do {} while (0)
-#endif
 // Inclusive scans across the 64 lanes on the DPP network (no LDS traffic): within rows of 16 by row_shr 1, 2, 4, 8, then
 // row 0's total into row 1 and row 2's into row 3 (row_bcast:15), then the lower half's total into the upper (row_bcast:31).
 #define RT_DPP_SCAN(v, OP)                                                                                      \
@@ -337,9 +329,6 @@ __device__ __forceinline__ void wave_visit_runs(uint32_t* mark, const float4* __
 	const int lane = lane_id();
 	uint32_t len = r1 > r0 ? r1 - r0 : 0u;
 	uint64_t longm = __ballot(len >= RT_GATHER_LONG);
-	RT_PROBE_ADD(0, 1);
-	RT_PROBE_ADD(4, __popcll(longm));
-	RT_PROBE_ADD(5, wave_sum_u(len >= RT_GATHER_LONG ? len : 0u));
 	while (longm) {
 		const int src = __ffsll((unsigned long long)longm) - 1;
 		longm &= longm - 1;
@@ -360,10 +349,6 @@ __device__ __forceinline__ void wave_visit_runs(uint32_t* mark, const float4* __
 	if (len >= RT_GATHER_LONG) len = 0u;
 	const uint32_t end = wave_scan_add_u32(len);   // inclusive prefix sum over the lanes
 	const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
-	RT_PROBE_ADD(1, total > 0u);
-	RT_PROBE_ADD(2, (total + 255u) / 256u);
-	RT_PROBE_ADD(3, total);
-	RT_PROBE_ADD(6, __popcll(__ballot(len > 0u)));
 	const uint32_t base = r0 - (end - len);   // slot of flattened element e inside this lane's run = base + e
 	// Each lane takes FOUR consecutive elements of the concatenation per round.  Which run an element belongs to: every
 	// non-empty run that starts inside the round's 256 elements writes its lane number + 1 into a byte table at its start
@@ -442,9 +427,7 @@ __device__ __forceinline__ void wave_visit_runs(uint32_t* mark, const float4* __
 // The walk of for_each_neighbour with a whole wave on one point (P and rho are wave-uniform): the grid rows of the cube
 // are dealt to the lanes, 64 at a time, each lane looks up its row's run, and the wave visits the 64 runs together.
 // f(slot, l2, active) runs in uniform control flow, `active` false in the padding.
-#ifndef RT_GATHER_MARKS_SEL   // probe builds: 1 = the selection's sweeps use the byte table too
 #define RT_GATHER_MARKS_SEL 0
-#endif
 template <bool MARKS = (RT_GATHER_MARKS_SEL != 0), typename F>
 __device__ __forceinline__ void for_each_neighbour_wave(uint32_t* mark, const GridDesc& gd, const uint32_t* __restrict__ cell_start,
                                                         const float4* __restrict__ pos, f3 P, float rho, F f)
@@ -564,12 +547,8 @@ __device__ __forceinline__ void wave_shell_sweep(uint32_t* mark, const GridDesc&
 			if (!SECOND) nc_l += in ? 1 : 0;
 			mx_l = __uint_as_float(max(__float_as_uint(mx_l), in ? __float_as_uint(l2) : 0u));
 		};
-#ifndef RT_GATHER_NOVISIT   // probe builds: the row tables alone
 		wave_visit_runs<true>(mark, pos, a0, a1, visit);
 		if (__ballot(b1 > b0)) wave_visit_runs<true>(mark, pos, b0, b1, visit);
-#else
-		(void)visit;
-#endif
 	}
 }
 
@@ -752,22 +731,14 @@ __global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uin
 // the wave's (LDS atomics), and the control flow of the selection is wave-uniform.  Same passes, same
 // bins, same tie rule (photons at the k-th distance are taken in walk order) as the per-lane kernel;
 // only the order of the floating-point sum differs (lane partial sums, then a butterfly).
-#ifndef RT_GATHER_WAVES
 #define RT_GATHER_WAVES 4
-#endif
 // PHASE 1: pass 1 alone, (count, max_dist2) per queue entry into `p1`; PHASE 2: the selection and the sum, pass 1's
 // results read back; PHASE 0: everything in one kernel.  Two kernels because fused the kernel holds the live state of
 // both halves (it spilled ~100 VGPRs and 220 SGPRs at 4 waves/SIMD), and the two halves want different occupancies:
 // pass 1 streams photons, the selection is a chain of short dependent sweeps.
-#ifndef RT_GATHER_WAVES1
 #define RT_GATHER_WAVES1 RT_GATHER_WAVES
-#endif
-#ifndef RT_GATHER_WAVES2
 #define RT_GATHER_WAVES2 RT_GATHER_WAVES
-#endif
-#ifndef RT_GATHER_P1_WAVES   // waves per workgroup of the PHASE 1 kernel: consecutive queue entries side by side on one CU
 #define RT_GATHER_P1_WAVES 4
-#endif
 template <bool SHELL, int PHASE>
 __global__ __launch_bounds__(PHASE == 1 ? 64 * RT_GATHER_P1_WAVES : 64) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ? RT_GATHER_WAVES1 : PHASE == 2 ? RT_GATHER_WAVES2 : RT_GATHER_WAVES,
                                                                     PHASE == 1 ? RT_GATHER_WAVES1 : PHASE == 2 ? RT_GATHER_WAVES2 : RT_GATHER_WAVES)))
@@ -873,10 +844,6 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 			nc = __builtin_amdgcn_readfirstlane(__float_as_int(r.x));
 			max_dist2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r.y)));
 		}
-#if defined(RT_GATHER_STOP) && RT_GATHER_STOP == 1
-		if (lane == 0) st3(rgb + 3 * (size_t)i, mk3((float)nc, max_dist2, 0));
-		continue;
-#endif
 		uint32_t tau = 0xFFFFFFFFu;
 		int take_equal = 0x7fffffff;
 		float rho_sel = radius;
@@ -1023,10 +990,6 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 				take_equal = need - wave_sum_i(less);
 			}
 		}
-#if defined(RT_GATHER_STOP) && RT_GATHER_STOP == 2
-		if (lane == 0) st3(rgb + 3 * (size_t)i, mk3((float)nc, max_dist2, __uint_as_float(tau)));
-		continue;
-#endif
 		// pass 3 (unless the sweep above has summed already)
 		if (nc > 0 && !summed) {
 			const float denom2 = 2.0f * max_dist2;
@@ -1064,12 +1027,8 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 // Every other case (fewer photons than wanted, an estimate that fell short, a crowded bin) is queued for PHASE 2 of
 // k_photon_gather_wave, which handles all of them.  Same bins, same tie rule, same results; the point of a kernel of its
 // own is its size: the general kernel carries eight inlined sweeps, holds 220 VGPRs and spills at 4 waves per SIMD.
-#ifndef RT_GATHER_WAVES2C
 #define RT_GATHER_WAVES2C 6
-#endif
-#ifndef RT_GATHER_MARKS_COMMON   // probe builds: 0 = the binary-search flattening in this kernel
 #define RT_GATHER_MARKS_COMMON 1
-#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_GATHER_WAVES2C, RT_GATHER_WAVES2C)))
 void k_photon_select_common(GridDesc gd, const uint32_t* __restrict__ cell_start, const float4* __restrict__ pos,
                             const float4* __restrict__ payload, const float* __restrict__ qpos, const float* __restrict__ qnrm,
@@ -1346,9 +1305,7 @@ static int build_one_grid(rt_hip_ctx* ctx, const PhotonRec* ph, int64_t n, const
 	return RT_HIP_OK;
 }
 
-#ifndef RT_FINE_CELL_CAP_LOG2
 #define RT_FINE_CELL_CAP_LOG2 26
-#endif
 int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 {
 	hipStream_t st = ctx->stream;
@@ -1375,11 +1332,6 @@ int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 	RT_CHECK(build_one_grid(ctx, ph, n, mn, mx, radius / (float)ctx->tuning.gather_fine_cells, (double)(1ll << RT_FINE_CELL_CAP_LOG2), ctx->d_photons_f, ctx->d_photon_sorted_f,
 	                        ctx->d_cell_start_f, ctx->photon_grid_dim_f, &ctx->photon_cell_f, ctx->photon_grid_min_f));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
-#ifdef RT_GATHER_PROBE
-	fprintf(stderr, "photon grids: bounds [%g %g %g]-[%g %g %g], coarse cell %g (%d x %d x %d), fine cell %g (%d x %d x %d)\n", mn[0], mn[1], mn[2],
-	        mx[0], mx[1], mx[2], ctx->photon_cell, ctx->photon_grid_dim[0], ctx->photon_grid_dim[1], ctx->photon_grid_dim[2], ctx->photon_cell_f,
-	        ctx->photon_grid_dim_f[0], ctx->photon_grid_dim_f[1], ctx->photon_grid_dim_f[2]);
-#endif
 	ctx->num_photons = n;
 	return RT_HIP_OK;
 }
@@ -1401,10 +1353,9 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 	// on the device).  tuning.gather_heavy is the threshold (0: every point with a photon nearby takes
 	// the wave kernel; a huge value: none does) -- the parity tests run both extremes.
 	const uint32_t heavy = ctx->tuning.gather_heavy;
-#ifndef RT_GATHER_MEDIUM   // wave kernel, pass 1: at most this many photons in the coarse cube -> read them all from the coarse grid
-#define RT_GATHER_MEDIUM 4096
-#endif
-	const uint32_t medium = RT_GATHER_MEDIUM;
+	// wave kernel, pass 1: at most this many photons in the coarse cube -> all of them are read from the coarse grid;
+	// 0 = never, every queued point walks the fine grid's boundary shell (tests force either path)
+	const uint32_t medium = ctx->tuning.gather_medium;
 	// counts (16 ints) | heavy queue (npts, padded to even) | pass-1 results (npts + 1 float2) | sub-queue (npts)
 	RT_CHECK(ctx->d_heavy.reserve(((size_t)2 * npts + 16 + 2) * sizeof(int) + ((size_t)npts + 1) * sizeof(float2)));
 	int* heavy_count = ctx->d_heavy.as<int>();
@@ -1434,21 +1385,11 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 			GridDesc gf;
 			for (int k = 0; k < 3; ++k) { gf.mn[k] = ctx->photon_grid_min_f[k]; gf.dim[k] = ctx->photon_grid_dim_f[k]; }
 			gf.cell = ctx->photon_cell_f; gf.inv_cell = 1.0f / ctx->photon_cell_f;
-#ifdef RT_GATHER_FUSED
-			hipLaunchKernelGGL((k_photon_gather_wave<true, 0>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
-			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
-#else
 			const int chunk1 = std::max(1, chunk / RT_GATHER_P1_WAVES), unit1 = 8 * chunk1;
 			const int blocks1 = ((std::min(npts, 64 * 1024) + RT_GATHER_P1_WAVES - 1) / RT_GATHER_P1_WAVES + unit1 - 1) / unit1 * unit1;
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 1>), dim3(blocks1), dim3(64 * RT_GATHER_P1_WAVES), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
 			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
-#ifdef RT_GATHER_NO_COMMON   // probe builds: every heavy point through the general kernel
-			hipLaunchKernelGGL((k_photon_gather_wave<true, 2>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
-			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
-#else
 			// the usual heavy point in the lean kernel; what it declines, in the general one
 			hipLaunchKernelGGL(k_photon_select_common, dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), d_pos, d_nrm, heavy_queue, heavy_count, count,
@@ -1456,8 +1397,6 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 2>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
 			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)sub_queue, (const int*)sub_count, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
-#endif
-#endif
 		} else {
 			hipLaunchKernelGGL((k_photon_gather_wave<false, 0>), dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
 			                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->num_photons, d_pos, d_nrm,
@@ -1494,12 +1433,3 @@ int rt_photon_unpermute(rt_hip_ctx* ctx, float* d_out)
 	return RT_HIP_OK;
 }
 
-#ifdef RT_GATHER_PROBE
-extern "C" int rt_hip_debug_gather_probe(unsigned long long* out8, int reset)
-{
-	unsigned long long z[16] = {};
-	if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gather_probe), sizeof(z)) != hipSuccess) return -1;
-	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_gather_probe), z, sizeof(z)) != hipSuccess) return -1;
-	return 0;
-}
-#endif

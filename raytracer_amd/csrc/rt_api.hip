@@ -94,6 +94,8 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->gather_fine = env_int("RT_HIP_GATHER_FINE", 1);
 	t->gather_xcd_chunk = env_int("RT_HIP_GATHER_XCD_CHUNK", 1024);
 	t->gather_fine_cells = env_int("RT_HIP_GATHER_FINE_CELLS", 8);
+	t->gather_medium = 4096;
+	if (const char* e = getenv("RT_HIP_GATHER_MEDIUM")) t->gather_medium = (uint32_t)strtoul(e, nullptr, 10);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);

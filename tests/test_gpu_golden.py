@@ -11,6 +11,7 @@ from test_oracle_golden import SCENES, groups, load, scene_for
 
 pytestmark = pytest.mark.gpu
 MISS = 0xFFFFFFFF
+ID_MISMATCHES_VS_DACRT = {"cornell": 2, "atrium2k": 0, "atrium2k_xf": 0, "atrium8k": 0}
 
 
 @pytest.mark.parametrize("name", ["cornell", "atrium2k", "atrium2k_xf", "atrium8k"])
@@ -30,7 +31,10 @@ def test_process_rays_vs_reference_vectors(name, accel):
     # ids: north_star's bar -- every mismatch is a bit-equal-t tie between triangles that share an edge
     rate = assert_only_edge_ties(sc, r["tidx"][hit], g["tidx"][hit], r["t"][hit], g["t"][hit],
                                  "golden/process_%s/accel%d vs DACRT" % (name, accel))
-    assert rate >= 0.99
+    # ... and the stated figures (profiles/r2_parity_id_match.json): none on the atrium fixtures, 2 of
+    # 14,764 hit rays on Cornell (99.9865 %; both bit-equal-t shared-edge ties, which assert_only_edge_ties has just
+    # proved).  The HIP id is the lowest of the tied ones whatever the builder, so the count is exact, not a bound.
+    assert int((~same[hit]).sum()) == ID_MISMATCHES_VS_DACRT[name], (name, int((~same[hit]).sum()), rate)
     both = hit & same
     assert_bits_equal(r["u"][both], g["u"][both], "u")
     assert_bits_equal(r["v"][both], g["v"][both], "v")

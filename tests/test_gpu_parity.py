@@ -800,3 +800,38 @@ def test_far_origins_bvh_equals_exhaustive(rt, accel, spread):
         # 1 ray in 31,541 finds a neighbour at the same t.
         assert (~same).sum() <= 3
     assert_bits_equal(a["hits"]["t"][hit][same], b["hits"]["t"][hit][same], "t")
+
+
+@pytest.mark.parametrize("accel", [2, 3], ids=["lbvh", "ploc"])
+def test_tuning_change_while_only_tables_are_dirty(rt, accel):
+    """rt_hip_set_tuning resizes the HBM part of the traversal stacks at once, also when the scene is dirty for
+    tables only (rt_hip_set_lights / _materials / _model_mat before the next update): a smaller LDS depth or a larger
+    grid cap otherwise pushes past the old array (round-2 advisor finding).  lds_stack_depth = 2 sends nearly every
+    push to HBM, trace_oversub = 16 quadruples the columns; results must still equal the exhaustive search."""
+    sc = scenes.atrium(2048)
+    rng = np.random.RandomState(3)
+    n = 1 << 15
+    allv = np.concatenate([m.verts for m in sc.meshes], 0)
+    lo, hi = allv.min(0), allv.max(0)
+    c, e = (lo + hi) / 2, (hi - lo) / 2
+    o = (c + rng.uniform(-1, 1, (n, 3)) * e).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    ref = rt.RtHip(sc, semantics="array", accel=1)
+    a = ref.intersect(rays)
+    ref.close()
+    g = rt.RtHip(sc, semantics="array", accel=accel)
+    g.intersect(rays[:64])                     # a first trace with the default tuning: the overflow array has its default size
+    g.load_scene_tables(sc)                    # dirty for tables only
+    g.set_tuning(lds_stack_depth=2, trace_oversub=16)
+    g.update()
+    assert g.stats()["last_update"] == rt.UPDATE_TABLES
+    b = g.intersect(rays)
+    occ = g.occlude(rays[:4096])
+    g.close()
+    np.testing.assert_array_equal(a["hit"], b["hit"])
+    hit = a["hit"] > 0
+    assert hit.sum() > n // 20
+    np.testing.assert_array_equal(a["hits"]["prim"][hit], b["hits"]["prim"][hit])
+    assert_bits_equal(a["hits"]["t"][hit], b["hits"]["t"][hit], "t")
+    assert occ.shape[0] == 4096

@@ -55,12 +55,16 @@ def test_emission_is_shard_invariant(oracle_cls):
     g.close()
 
 
+@pytest.mark.parametrize("medium", [None, 0], ids=["medium-default", "shell-walk-forced"])
 @pytest.mark.parametrize("heavy", [None, 0, 4000000000], ids=["default-split", "all-wave", "all-lane"])
 # (400, ...): more photons wanted than the wave kernels queue in LDS for the sum (256): the overflow branch sums on the spot
 @pytest.mark.parametrize("count,radius", [(100, 1.0), (50, 3.0), (7, 0.5), (400, 3.0), (400, 0.7)])
-def test_gather_matches_oracle(oracle_cls, count, radius, heavy):
+def test_gather_matches_oracle(oracle_cls, count, radius, heavy, medium):
     """Both gather kernels against the oracle: by default a point goes to the wave-per-point kernel when its
-    cube holds more than tuning.gather_heavy (32) photons; tuning.gather_heavy = 0 / huge sends every point one way."""
+    cube holds more than tuning.gather_heavy (32) photons; tuning.gather_heavy = 0 / huge sends every point one way.
+    tuning.gather_medium = 0 forces every queued point through the fine grid's shell walk (interiors counted from the
+    cell table) + the lean selection kernel -- the path that at full size only the densest points take; the default
+    (4096) reads these small neighbourhoods whole from the coarse grid instead."""
     import raytracer_amd as rt
     sc = scenes.cornell()
     orc = oracle_cls(sc)
@@ -73,6 +77,9 @@ def test_gather_matches_oracle(oracle_cls, count, radius, heavy):
     if heavy is not None:
         g.set_tuning(gather_heavy=heavy)
         assert g.tuning()["gather_heavy"] == heavy
+    if medium is not None:
+        g.set_tuning(gather_medium=medium)
+        assert g.tuning()["gather_medium"] == medium
     g.photon_set(ph)
     got = g.radiance_estimate(pos, nrm, count, radius)
     np.testing.assert_array_equal(np.isnan(exp), np.isnan(got))   # the empty-neighbourhood NaN (rt_photon_map.cpp:204)
@@ -87,8 +94,9 @@ def test_gather_matches_oracle(oracle_cls, count, radius, heavy):
     g.close()
 
 
+@pytest.mark.parametrize("medium", [4096, 0], ids=["medium-default", "shell-walk-forced"])
 @pytest.mark.parametrize("heavy", [0, 4000000000], ids=["all-wave", "all-lane"])
-def test_gather_ties_at_the_kth_distance(oracle_cls, heavy):
+def test_gather_ties_at_the_kth_distance(oracle_cls, heavy, medium):
     """Every photon stored three times: the k-th distance is shared by photons of which only some may be taken
     (k = 100 is not a multiple of 3).  The copies are identical, so whichever the reference's unstable sort keeps,
     the sum is the same; both kernels must take exactly k."""
@@ -100,7 +108,7 @@ def test_gather_ties_at_the_kth_distance(oracle_cls, heavy):
     pos, nrm, _ = orc.gbuffer_select(nr, po)
     orc.photon_set(ph)
     exp = orc.radiance_estimate(pos, nrm, 100, 1.5)
-    g = rt.RtHip(sc, semantics="array", photon_radius=1.5, tuning=dict(gather_heavy=heavy))
+    g = rt.RtHip(sc, semantics="array", photon_radius=1.5, tuning=dict(gather_heavy=heavy, gather_medium=medium))
     g.photon_set(ph)
     got = g.radiance_estimate(pos, nrm, 100, 1.5)
     ok = ~np.isnan(exp)
