@@ -280,17 +280,22 @@ int rt_hip_trace_any_device(rt_hip_ctx* ctx, const float* d_org, const float* d_
 int rt_hip_gbuffer_select_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n,
                                  int interlace, int phase, float* d_positions_out, float* d_normals_out,
                                  int* d_index_out, int* out_count);
-/* The same selection for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference.
+/* The same selection for callers that cannot allocate device memory (tight serving loops, harnesses that
+ * forbid hipMalloc, code under HIP graph capture).  It has NO counterpart in the reference.
  * Same arguments, same outputs bit for bit and the same stable order as rt_hip_gbuffer_select_device,
  * but it calls no hipMalloc / hipFree: its only scratch (one count per 2048-texel tile, 33 KB) is a
  * fixed file-scope device array that each GPU holds from the first rt_hip_create on it until the
  * process ends.  n beyond RT_HIP_NOALLOC_MAX_TEXELS fails with RT_HIP_ERR_LIMIT.  The array is shared
- * by every context on a GPU: calls that overlap on one GPU (two contexts, two threads) race. */
+ * by every context on a GPU: calls that overlap on one GPU (two contexts, two threads) race.
+ * Where the count goes: d_count_out (device word of the caller, may be null) receives it from the scan
+ * kernel; out_count (host, may be null) additionally through a 4-byte device-to-host copy and a stream
+ * synchronisation.  With out_count == NULL the call is three kernel launches on the context's stream and
+ * nothing else -- no copy, no wait -- which is the form a capturing stream takes; with out_count != NULL
+ * it is not legal under capture (the copy and the wait are not).  At least one of the two must be given. */
 #define RT_HIP_NOALLOC_MAX_TEXELS (1 << 24)
 int rt_hip_gbuffer_select_noalloc_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n,
                                          int interlace, int phase, float* d_positions_out, float* d_normals_out,
-                                         int* d_index_out, int* out_count);
+                                         int* d_index_out, int* d_count_out, int* out_count);
 /* Software G-buffer producer: primary rays with Camera::getScreenRays
  * geometry (data/camera.cpp:19-44), closest hit, prepass_fs encodings (UNORM16 normal, FP16
  * position; prepass_fs.cpp:11-13, ras_rasterizer.cpp:293,301); alpha = material id + 1, 0 = empty. */

@@ -141,7 +141,7 @@ def load_library() -> C.CDLL:
     L.rt_hip_trace_any_device.argtypes = [P, P, P, C.c_int, P]
     L.rt_hip_trace_census_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
     L.rt_hip_gbuffer_select_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, c_int_p]
-    L.rt_hip_gbuffer_select_noalloc_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, c_int_p]
+    L.rt_hip_gbuffer_select_noalloc_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, c_int_p]
     L.rt_hip_render_gbuffer_device.argtypes = [P, C.c_float, C.c_int, C.c_int, P, P]
     L.rt_hip_render_gbuffer_uv_device.argtypes = [P, C.c_float, C.c_int, C.c_int, P, P, P]
     L.rt_hip_set_texture.argtypes = [P, C.c_int, P, C.c_int, C.c_int]
@@ -436,11 +436,16 @@ class RtHip:
                                                        _dptr(d_pos_out), _dptr(d_nrm_out), _dptr(d_index_out), C.byref(cnt)))
         return cnt.value
 
-    def gbuffer_select_noalloc_device(self, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_pos_out, d_nrm_out, d_index_out):
-        """The allocation-free variant (fixed per-GPU scratch, n <= 2^24)."""
+    def gbuffer_select_noalloc_device(self, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_pos_out, d_nrm_out, d_index_out, d_count=None):
+        """The allocation-free variant (fixed per-GPU scratch, n <= 2^24).  With d_count (a device int) the count stays on
+        the device and nothing is copied or waited for (returns None); otherwise the count is returned."""
+        if d_count is not None:
+            self._ck(self.lib.rt_hip_gbuffer_select_noalloc_device(self.h, _dptr(d_nrm_rgba), _dptr(d_pos_rgb), n, interlace, phase,
+                                                                   _dptr(d_pos_out), _dptr(d_nrm_out), _dptr(d_index_out), _dptr(d_count), None))
+            return None
         cnt = C.c_int(0)
         self._ck(self.lib.rt_hip_gbuffer_select_noalloc_device(self.h, _dptr(d_nrm_rgba), _dptr(d_pos_rgb), n, interlace, phase,
-                                                               _dptr(d_pos_out), _dptr(d_nrm_out), _dptr(d_index_out), C.byref(cnt)))
+                                                               _dptr(d_pos_out), _dptr(d_nrm_out), _dptr(d_index_out), None, C.byref(cnt)))
         return cnt.value
 
     def render_gbuffer_device(self, fov, w, h, d_nrm_rgba, d_pos_rgb):

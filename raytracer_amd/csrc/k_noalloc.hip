@@ -9,6 +9,8 @@
 // own address) and keeps the previous call's contents: every word a call reads it has written
 // first (tile counts [0, nb), the total behind them), so nothing has to start at zero.  Calls that
 // overlap on one GPU -- two contexts, two threads -- race on it.
+#include <mutex>
+
 #include "rt_ctx.h"
 
 namespace {
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(NA_WAVE) void k_na_count(const float* __restrict__ 
 }
 
 // one workgroup: exclusive scan of the nb tile counts in place, total to tile_count[NA_MAX_TILES]
-__global__ __launch_bounds__(NA_SCAN_BLOCK) void k_na_scan(uint32_t* __restrict__ tile_count, int nb)
+__global__ __launch_bounds__(NA_SCAN_BLOCK) void k_na_scan(uint32_t* __restrict__ tile_count, int nb, int* __restrict__ count_out)
 {
 	__shared__ uint32_t wsum[NA_SCAN_BLOCK / 64];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(NA_SCAN_BLOCK) void k_na_scan(uint32_t* __restrict_
 		carry += tot;
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) tile_count[NA_MAX_TILES] = carry;
+	if (threadIdx.x == 0) { tile_count[NA_MAX_TILES] = carry; if (count_out) *count_out = (int)carry; }
 }
 
 // one wave per tile: kept texels go to tile start + rank inside the tile (ascending texel index: stable)
@@ -103,6 +105,8 @@ __global__ __launch_bounds__(NA_WAVE) void k_na_scatter(const float* __restrict_
 int rt_noalloc_setup(int device)
 {
 	if (device < 0 || device >= NA_MAX_DEVICES) { rt_set_error("device %d beyond the %d the no-alloc entry keeps scratch for", device, NA_MAX_DEVICES); return RT_HIP_ERR_LIMIT; }
+	static std::mutex mu;  // contexts may be created from several threads at once
+	std::lock_guard<std::mutex> lock(mu);
 	if (g_scratch_ptr[device]) return RT_HIP_OK;
 	uint32_t* p = nullptr;
 	RT_HIP_CHECK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
@@ -111,11 +115,12 @@ int rt_noalloc_setup(int device)
 	return RT_HIP_OK;
 }
 
+// out_count == nullptr: nothing is copied to the host and nothing is waited for -- the three kernels are the whole call,
+// which is what makes it legal on a capturing stream; the count is then left in *d_count_out (device memory of the caller).
 int rt_gbuffer_select_noalloc(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n, int interlace,
-                              int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* out_count)
+                              int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* d_count_out, int* out_count)
 {
-	*out_count = 0;
-	if (n <= 0) return RT_HIP_OK;
+	if (out_count) *out_count = 0;
 	if (n > RT_HIP_NOALLOC_MAX_TEXELS) {
 		rt_set_error("rt_hip_gbuffer_select_noalloc_device: %d texels exceed the fixed scratch (at most %d)", n, RT_HIP_NOALLOC_MAX_TEXELS);
 		return RT_HIP_ERR_LIMIT;
@@ -124,12 +129,13 @@ int rt_gbuffer_select_noalloc(rt_hip_ctx* ctx, const float* d_nrm_rgba, const fl
 	uint32_t* sp = (device >= 0 && device < NA_MAX_DEVICES) ? g_scratch_ptr[device] : nullptr;
 	if (!sp) { rt_set_error("no-alloc scratch of device %d was not set up", device); return RT_HIP_ERR_STATE; }
 	hipStream_t st = ctx->stream;
-	const int nb = (n + NA_TILE - 1) / NA_TILE;
-	hipLaunchKernelGGL(k_na_count, dim3(nb), dim3(NA_WAVE), 0, st, d_nrm_rgba, n, interlace, phase, sp);
-	hipLaunchKernelGGL(k_na_scan, dim3(1), dim3(NA_SCAN_BLOCK), 0, st, sp, nb);
-	hipLaunchKernelGGL(k_na_scatter, dim3(nb), dim3(NA_WAVE), 0, st, d_nrm_rgba, d_pos_rgb, n, interlace, phase, sp, d_pos_out,
-	                   d_nrm_out, d_index_out);
+	const int nb = (n + NA_TILE - 1) / NA_TILE;   // n == 0: the scan alone, which leaves a count of 0
+	if (nb > 0) hipLaunchKernelGGL(k_na_count, dim3(nb), dim3(NA_WAVE), 0, st, d_nrm_rgba, n, interlace, phase, sp);
+	hipLaunchKernelGGL(k_na_scan, dim3(1), dim3(NA_SCAN_BLOCK), 0, st, sp, nb, d_count_out);
+	if (nb > 0) hipLaunchKernelGGL(k_na_scatter, dim3(nb), dim3(NA_WAVE), 0, st, d_nrm_rgba, d_pos_rgb, n, interlace, phase, sp, d_pos_out,
+	                               d_nrm_out, d_index_out);
 	RT_HIP_CHECK(hipGetLastError());
+	if (!out_count) return RT_HIP_OK;
 	// the count comes back through the context's pinned word (allocated by rt_hip_create)
 	uint32_t* h_cnt = (uint32_t*)ctx->h_small;
 	RT_HIP_CHECK(hipMemcpyAsync(h_cnt, sp + NA_MAX_TILES, 4, hipMemcpyDeviceToHost, st));

@@ -248,6 +248,17 @@ int rt_collect_timing(rt_hip_ctx* ctx, size_t upto)
 	}
 	ctx->trace_events_collected = std::max(ctx->trace_events_collected, end);
 	if (ctx->trace_events_collected >= ctx->trace_events_used) ctx->trace_events_used = ctx->trace_events_collected = 0;
+	else if (ctx->trace_events_collected > 0) {
+		// The frame pipeline keeps one frame's launches recorded ahead, so the pool never drains completely: move the
+		// live tail [collected, used) to the front and reuse the folded pairs, instead of creating new events for every
+		// frame (the pool is then as large as two frames' launches, for any number of frames).
+		const size_t shift = ctx->trace_events_collected;
+		std::rotate(ctx->trace_events.begin(), ctx->trace_events.begin() + shift, ctx->trace_events.begin() + ctx->trace_events_used);
+		std::rotate(ctx->trace_event_class.begin(), ctx->trace_event_class.begin() + shift, ctx->trace_event_class.begin() + ctx->trace_events_used);
+		ctx->trace_events_used -= shift;
+		ctx->trace_events_collected = 0;
+		for (PendingFrame& pf : ctx->pending) pf.trace_mark = pf.trace_mark > shift ? pf.trace_mark - shift : 0;
+	}
 	if (ctx->cfg.census && ctx->d_census.p) {
 		unsigned long long c[7];
 		RT_HIP_CHECK(hipMemcpy(c, ctx->d_census.p, sizeof(c), hipMemcpyDeviceToHost));
@@ -806,14 +817,15 @@ int rt_hip_gbuffer_select_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const
 
 int rt_hip_gbuffer_select_noalloc_device(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n, int interlace,
                                          int phase, float* d_positions_out, float* d_normals_out, int* d_index_out,
-                                         int* out_count)
+                                         int* d_count_out, int* out_count)
 {
 	RT_CHECK(check_ctx(ctx));
-	if (n < 0 || !out_count || (n > 0 && (!d_nrm_rgba || !d_pos_rgb || !d_positions_out || !d_normals_out))) {
+	if (n < 0 || (!out_count && !d_count_out) || (n > 0 && (!d_nrm_rgba || !d_pos_rgb || !d_positions_out || !d_normals_out))) {
 		rt_set_error("bad arguments");
 		return RT_HIP_ERR_ARG;
 	}
-	return rt_gbuffer_select_noalloc(ctx, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_positions_out, d_normals_out, d_index_out, out_count);
+	return rt_gbuffer_select_noalloc(ctx, d_nrm_rgba, d_pos_rgb, n, interlace, phase, d_positions_out, d_normals_out, d_index_out,
+	                                 d_count_out, out_count);
 }
 
 int rt_hip_render_gbuffer_device(rt_hip_ctx* ctx, float fov, int width, int height, float* d_nrm_rgba, float* d_pos_rgb)

@@ -273,7 +273,7 @@ int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_byt
 // ---- k_noalloc.hip -------------------------------------------------------------------------------
 int rt_noalloc_setup(int device);  // once per device, that device current
 int rt_gbuffer_select_noalloc(rt_hip_ctx* ctx, const float* d_nrm_rgba, const float* d_pos_rgb, int n, int interlace,
-                              int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* out_count);
+                              int phase, float* d_pos_out, float* d_nrm_out, int* d_index_out, int* d_count_out, int* out_count);
 
 // ---- k_photon.hip --------------------------------------------------------------------------------
 int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count, float* d_out, int64_t capacity,

@@ -17,25 +17,38 @@ PHOTON_FLOATS = 9  # position, energy, direction
 
 
 def gather_photons(local: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather of (k_r, 9) float32 photon arrays, ranks in order.  Two collectives: the counts
-    (one int64 per rank), then the payload padded to the largest shard (all_gather needs equal
-    shapes; the padding is at most one shard and is dropped on arrival)."""
+    """All-gather of (k_r, 9) float32 photon arrays, ranks in order, EXACT sizes -- the same exchange as the C route
+    (rt_hip_photon_generate_multi, k_comm.hip): an all-gather of the counts (one int64 per rank), then every rank
+    sends its shard to every peer and receives each peer's shard straight into its place in the output, as one batch
+    of point-to-point operations (RCCL: one grouped ncclSend / ncclRecv set, each xGMI link carries one shard; gloo in
+    the CPU tests).  Nothing is padded: a rank moves (world - 1) x its own shard out and the other shards in."""
     assert local.dim() == 2 and local.shape[1] == PHOTON_FLOATS and local.dtype == torch.float32
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     # the nccl (RCCL) backend needs device tensors, gloo needs host tensors: keep `local`'s device
     counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
     counts = [int(c.item()) for c in counts]
-    kmax = max(counts)
-    if kmax == 0:
-        return local[:0]
-    padded = torch.zeros((kmax, PHOTON_FLOATS), dtype=torch.float32, device=local.device)
-    padded[: local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    return torch.cat([p[:c] for p, c in zip(parts, counts)], 0).contiguous()
+    offsets = [0]
+    for c in counts:
+        offsets.append(offsets[-1] + c)
+    out = torch.empty((offsets[-1], PHOTON_FLOATS), dtype=torch.float32, device=local.device)
+    local = local.contiguous()
+    out[offsets[rank]:offsets[rank + 1]] = local
+    ops = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+        if counts[rank] > 0:
+            ops.append(dist.P2POp(dist.isend, local, gpeer, group))
+        if counts[peer] > 0:
+            ops.append(dist.P2POp(dist.irecv, out[offsets[peer]:offsets[peer + 1]], gpeer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
 
 
 def build_photon_map(ctx, per_light: int, num_lights: int, device, group=None):

@@ -70,6 +70,36 @@ def test_gbuffer_select_noalloc_matches_allocating_entry(oracle_cls):
     _assert_same(a4, b4, "second context")
     g2.close()
 
+    # the count left on the device: no copy, no wait -- the form a capturing stream takes
+    o_p = torch.full((n * 3,), -7.0, dtype=torch.float32, device="cuda")
+    o_n = torch.full((n * 3,), -7.0, dtype=torch.float32, device="cuda")
+    o_i = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    d_cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    assert g.gbuffer_select_noalloc_device(d_n, d_p, n, 16, 0, o_p, o_n, o_i, d_count=d_cnt) is None
+    g.sync()
+    _assert_same((int(d_cnt.item()), o_p.cpu().numpy(), o_n.cpu().numpy(), o_i.cpu().numpy()), a3, "count on the device")
+    # ... and actually captured into a HIP graph on the context's stream, then replayed on a changed G-buffer
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    stream = ctypes.c_void_p(g.stream())
+    graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()
+    d_n2 = d_n.clone()
+    o_p.fill_(-7.0); o_n.fill_(-7.0); o_i.fill_(-7); d_cnt.fill_(-1)
+    torch.cuda.synchronize()
+    assert hip.hipStreamBeginCapture(stream, 2) == 0          # hipStreamCaptureModeRelaxed
+    # (the binding's un-fenced form: its wrapper would synchronise the stream around the C call)
+    type(g).gbuffer_select_noalloc_device.__wrapped__(g, d_n2, d_p, n, 16, 0, o_p, o_n, o_i, d_count=d_cnt)
+    assert hip.hipStreamEndCapture(stream, ctypes.byref(graph)) == 0, "the call is not legal under capture"
+    assert hip.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+    assert int(d_cnt.item()) == -1                             # captured, not executed
+    d_n2.view(-1, 4)[: n // 2, 3] = 0.0                        # the replay sees the buffer's contents at launch time
+    torch.cuda.synchronize()
+    assert hip.hipGraphLaunch(gexec, stream) == 0
+    g.sync()
+    ref_cnt = g.gbuffer_select_device(d_n2, d_p, n, 16, 0, *(torch.empty_like(t) for t in (o_p, o_n, o_i)))
+    assert int(d_cnt.item()) == ref_cnt and 0 < ref_cnt < a3[0]
+    hip.hipGraphExecDestroy(gexec); hip.hipGraphDestroy(graph)
+
     # empty input and the documented limit
     assert g.gbuffer_select_noalloc_device(d_n, d_p, 0, 1, 0, d_p, d_p, d_p) == 0
     with pytest.raises(rt.RtHipError, match="exceed"):
