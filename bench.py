@@ -47,6 +47,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
+L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s over the 8 XCDs
+L1_PEAK_GBS = 39321.6            # 64 B/clk/CU x 256 CUs x 2.4 GHz
 VALU_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 vector peak (packed / dual-issue FMA on every lane)
 VALU_UNPACKED_TFLOPS = 78.6      # plain per-lane v_fma_f32: what scalar-per-lane ray code can issue
 NODE_FLOP, TRI_FLOP = 34.0, 45.0  # per node visit: 12 FMA (24) + 8 min/max + 2 compares for both child boxes; per triangle test: Moeller-Trumbore up to t
@@ -71,7 +73,7 @@ def offline_counters(workload, shadow_mode, accel, photons):
     """The rocprofv3 --pmc passes of this same command (scripts/profile_round.sh writes the summary; counters
     cannot be read from inside the process being measured).  Returned only when the profile was taken on the
     same workload, builder and kernel sources; otherwise (None, why)."""
-    for name in (("r2_pmc_traffic_c5.json",) if photons else ("r2_pmc_traffic.json", "r1_pmc_traffic.json")):
+    for name in (("r3_pmc_traffic_c5.json", "r2_pmc_traffic_c5.json") if photons else ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -96,8 +98,13 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=0,
-                    help="sub-steps per step (0 = auto: 50, or 2 with --photons): sized so that the timed region lasts ~1 s")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+                    help="sub-steps per step (0 = auto: 300, or 2 with --photons): sized so that the timed region of the default run lasts "
+                         "more than 5 s (a driver-side GPU-busy sample 5 s apart lands in it)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): every sub-step is ONE frame, split over the N ranks (north_star's partition); weak: N frames per sub-step")
+    ap.add_argument("--route", default="cabi", choices=["cabi", "torch"],
+                    help="N > 1, strong: cabi = rt_hip_comm_init + rt_hip_render_frame_multi_device (RCCL called by the library, the route a C++ "
+                         "host takes; the unique id is broadcast over torch.distributed); torch = tiles.py / frames.py over torch.distributed")
     ap.add_argument("--workload", default="atrium-262k-1080p",
                     choices=["atrium-262k-1080p", "atrium-1m-1080p", "atrium-1m-4k", "cornell-1080p", "atrium-8k-small"])
     ap.add_argument("--shadow-mode", default="corrected", choices=["corrected", "literal"],
@@ -116,6 +123,16 @@ def parse_args():
                     help="skip the untimed extra figures (host-to-host and with-rebuild ms/frame, literal shadows, the 1M-triangle target config)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="G-buffer texels fed to the CPU baseline (0 = auto)")
     return ap.parse_args()
+
+
+_SCENES = {}
+
+
+def atrium_cached(scenes, tris):
+    """The 1 M-triangle stand-in takes seconds to generate on the host: made once per run."""
+    if tris not in _SCENES:
+        _SCENES[tris] = scenes.atrium(tris)
+    return _SCENES[tris]
 
 
 WORKLOADS = {
@@ -193,20 +210,33 @@ def main():
         g.update()
     build_stats = g.stats()
     photon_info = None
+    strong_cabi_early = args.scaling == "strong" and world > 1 and args.route == "cabi" and backend == "nccl"
+    if strong_cabi_early:
+        # one communicator per context, created by the library (ncclCommInitRank); only the 128-byte id travels through torch
+        def bcast(mine):
+            box = [mine]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        g.comm_init(rank, world, broadcast=bcast)
     if args.photons > 0:
         from raytracer_amd.photons import build_photon_map
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        nph = build_photon_map(g, args.photons, len(scene.lights), dev)
+        if strong_cabi_early:
+            nph = g.photon_generate_multi(args.photons)     # emit shard -> all-gather of counts -> grouped send / recv -> grid, all in the library
+        else:
+            nph = build_photon_map(g, args.photons, len(scene.lights), dev)
         g.sync()
         photon_info = {"photons_per_light": args.photons, "photons_stored": nph,
                        "photon_pass_ms": round((time.perf_counter() - t0) * 1e3, 3)}
 
-    strong = args.scaling == "strong" and world > 1
-    K = args.frames_per_step if args.frames_per_step > 0 else (2 if args.photons > 0 else 50)
+    strong = args.scaling == "strong"          # at N = 1 a label only: one frame per sub-step either way
+    # the library's own RCCL route needs one GPU per rank; the gloo rehearsal (all ranks on device 0) takes the torch route
+    cabi = strong and world > 1 and args.route == "cabi" and backend == "nccl"
+    K = args.frames_per_step if args.frames_per_step > 0 else (2 if args.photons > 0 else 300)
 
     # ---- inputs resident in HBM: one G-buffer per frame of a sub-step -------------------------
-    nframes = 1 if strong else world
+    nframes = 1 if (strong or world == 1) else world
     npix = W * H
     gb_n, gb_p = [], []
     for f in range(nframes):
@@ -223,15 +253,21 @@ def main():
     tiles = [torch.zeros(npix * 4, dtype=torch.uint8, device=dev) for _ in range(nframes)]   # this rank's tiles of each frame
     frame = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)    # N > 1: the frame assembled from all ranks' tiles
     xchg = None
-    if world > 1:
+    if world > 1 and not cabi:
         from raytracer_amd.frames import TileExchange, TileAllGather
         xchg = TileAllGather(g, W, H, 64, rank, world, dev) if strong else TileExchange(g, W, H, 64, rank, world, dev)
 
     render_batch = rt.RtHip.render_tiles_batch_device.__wrapped__
+    render_multi = rt.RtHip.render_frame_multi_device.__wrapped__
 
     def substep():
         # this rank's tiles of all the sub-step's frames in one wavefront (a batch of one at N = 1)
-        if strong:
+        if cabi:
+            # ONE C call per frame: own tiles shaded into the packed chunk, ncclAllGather, unpack; returns with the whole
+            # frame assembled on this rank (the call ends with a stream synchronisation)
+            render_multi(g, gb_p[0], gb_n[0], W, H, 64, frame)
+            rays = g.last_frame_rays()
+        elif strong and xchg:
             xchg.render(gb_p[0], gb_n[0])     # this rank's tiles of THE frame, packed
             rays = g.last_frame_rays()
             xchg.gather(frame)                # RCCL all-gather of the chunks + unpack: every rank holds the whole frame
@@ -262,7 +298,7 @@ def main():
         return sum(substep() for _ in range(K))
 
     def drain():
-        if xchg and not strong:
+        if xchg and not strong and world > 1:
             xchg.finish(frame)            # the last sub-step's exchange belongs to the timed region
 
     def fence():
@@ -343,7 +379,7 @@ def main():
 
     # ---- N > 1 (untimed): the frame assembled from all ranks' tiles == the same frame shaded whole on this rank ----
     tiles_verified = None
-    if xchg:
+    if xchg or cabi:
         whole = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)
         g.render_frame_device(gb_p[0 if strong else rank], gb_n[0 if strong else rank], W, H, whole)
         ok = torch.tensor([1.0 if torch.equal(whole, frame) else 0.0], dtype=torch.float64, device=red_dev)
@@ -351,13 +387,24 @@ def main():
         tiles_verified = bool(ok.item() == 1.0)
 
     # ---- untimed extras on rank 0 at N = 1: the spans SURVEY 8d defines around the device-resident frame ----
-    extras, target = {}, None
+    extras, target, more = {}, None, {}
     if rank == 0 and world == 1 and not args.no_extras and args.photons == 0 and inflight == 1:
         extras, target = run_extras(args, rt, scenes, g, scene, gb_p[0], gb_n[0], W, H, dev, dev_index, ACCEL)
+        more = run_more_configs(args, rt, scenes, g, scene, gb_p[0], gb_n[0], W, H, dev, dev_index, ACCEL, elapsed / frames_done * 1e3)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(scene, gb_n[0], gb_p[0], W, H, args.cpu_sample)
+        cpu_baseline = run_cpu_baseline(scene, gb_n[0], gb_p[0], W, H, args.cpu_sample, more.get("_ref_equiv_sample"))
+        re_cpu = cpu_baseline.pop("reference_equivalent", None)
+        if re_cpu and "reference_equivalent" in more:
+            more["reference_equivalent"]["cpu"] = re_cpu
+            gpu_ms = more["reference_equivalent"].get("gpu_host_pointers_ms")
+            if gpu_ms:
+                more["reference_equivalent"]["gpu_over_cpu_same_call_same_samples"] = round(re_cpu["ms"] / gpu_ms, 1)
+        if "process_rays_full_frame" in more:
+            more["process_rays_full_frame"]["cpu_mrays_per_s"] = cpu_baseline["value"]
+            more["process_rays_full_frame"]["cpu_note"] = "cpu_baseline.value: the same call (RayTracer::processRays) on a strided sample of the same texels, one thread"
+    more.pop("_ref_equiv_sample", None)
 
     if rank == 0:
         ms_per_frame = elapsed / frames_done * 1e3
@@ -366,7 +413,7 @@ def main():
             "metric": "secondary Mrays/s", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong" if strong else "weak",
+            "scaling": "strong" if strong else "weak",   # strong: total work fixed (one 1080p frame per sub-step, split over the ranks)
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload + ("+photons" if args.photons > 0 else ""), "scene": scene.name, "triangles": scene.num_tris, "width": W, "height": H,
                        "frames_per_step": K * nframes, "tile": 64, "bounces": 2, "lights": len(scene.lights),
@@ -379,21 +426,27 @@ def main():
                        "frame_latency_ms": round(latency, 4),
                        "ms_per_frame_definition": "ms_per_frame = wall time / frames completed by the whole job (G-buffer and image resident in "
                                                   "HBM, BVH build excluded); frame_latency_ms = first kernel to assembled image of one frame"
-                                                  + (" (= one frame split over all ranks + all-gather of its tiles)" if strong else
+                                                  + (" (= one frame split over all ranks + all-gather of its tiles)" if (strong and world > 1) else
                                                      " (at N > 1: of the N frames of one sub-step, rendered together)" if world > 1 else ""),
                        "timed_region_s": round(elapsed, 3),
                        "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"],
                        **extras,
-                       **({"exchange": ("all-gather of packed tiles after every frame" if strong else
+                       **({"multi_gpu_route": ("C ABI: rt_hip_comm_init (id broadcast over torch.distributed) + rt_hip_render_frame_multi_device: RCCL "
+                                               "all-gather of the packed tiles inside the library, every rank holds the whole frame" if cabi else
+                                               "torch.distributed: raytracer_amd/frames.py"),
+                           "exchange": ("all-gather of packed tiles after every frame" if strong else
                                         "all-to-all of packed tiles, overlapped with the next sub-step") if os.environ.get("BENCH_XCHG") is None else os.environ["BENCH_XCHG"],
-                           "assembled_frames_equal_whole_frames": tiles_verified} if xchg else {}),
+                           "assembled_frames_equal_whole_frames": tiles_verified} if (xchg or cabi) else {}),
                        **({"photon_map": photon_info} if photon_info else {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
         if target:
             out["target_config"] = target
+        out.update(more)
         print(json.dumps(out))
+    if cabi:
+        g.comm_destroy()
     g.close()
     if world > 1:
         dist.destroy_process_group()
@@ -408,7 +461,7 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
     # census pass: same frame(s), counting node visits / triangle tests per ray and photons per gather (untimed)
     g.set_config(census=1, profile=0)
     g.reset_stats()
-    if strong:
+    if strong and world > 1:
         g.render_tiles_device(gb_p[0], gb_n[0], W, H, 64, rank, world, tiles[0])
     else:
         g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
@@ -495,12 +548,23 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
         if t and avg_ms > 0:
             roof["hbm_counter_GBs"] = round(t / (avg_ms * 1e-3) / 1e9, 1)
             roof["hbm_frac"] = round(t / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        for k in ("valu_issue_frac", "lanes_active_frac", "ta_busy_frac", "td_busy_frac", "l1_hit_frac", "l2_hit_frac", "profiled_avg_launch_ms"):
+        # cache-level rates: requests x line size (offline counters) / this run's launch time, against the guide's L2 rate (34.5 TB/s over
+        # the 8 XCDs) and the L1s' 64 B/clk/CU x 256 CUs x 2.4 GHz
+        if counters.get("l2_request_bytes_per_launch") and avg_ms > 0:
+            roof["l2_GBs"] = round(counters["l2_request_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
+            roof["l2_frac"] = round(roof["l2_GBs"] / L2_PEAK_GBS, 4)
+        if counters.get("l1_request_bytes_per_launch") and avg_ms > 0:
+            roof["l1_GBs"] = round(counters["l1_request_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9, 1)
+            roof["l1_frac"] = round(roof["l1_GBs"] / L1_PEAK_GBS, 4)
+            roof["cache_rates_note"] = ("l1 / l2: requests x line size (TCP_TOTAL_CACHE_ACCESSES x 64 B, TCC_REQ x 128 B; upper bounds on the bytes moved) / launch time, "
+                                        "peaks %.0f GB/s (64 B/clk/CU x 256 CUs x 2.4 GHz) and %.0f GB/s (MI355X_MICROARCH.md, L2)" % (L1_PEAK_GBS, L2_PEAK_GBS))
+        for k in ("valu_issue_frac", "lanes_active_frac", "ta_busy_frac", "td_busy_frac", "l1_hit_frac", "l2_hit_frac", "wait_any_frac", "profiled_avg_launch_ms"):
             if k in counters:
                 roof[k] = counters[k]
     roof["counters_source"] = counters_note
-    roof.setdefault("bound_note", "per the counters the kernel is limited by vector-ALU issue together with the vector-memory pipeline (TA/TD), at "
-                                  "two thirds of the lanes active; HBM carries a few percent of its peak")
+    roof.setdefault("bound_note", "per the counters the kernel is limited by vector-ALU issue together with the vector-memory pipeline (TA/TD: each 16 B/lane load "
+                                  "occupies the CU's data return path for 16 cycles whatever the cache hit rate), at two thirds of the lanes active; HBM carries a "
+                                  "few percent of its peak")
     return roof
 
 
@@ -572,6 +636,32 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
                                               "PCIe under frame k's kernels; wall time / frames" % n)
     except Exception as e:
         cfg["host_to_host_pipelined_note"] = "not measured: %r" % (e,)
+    # ... and with the G-buffer in the FBO's own 16-bit formats (rt_hip_frame_enqueue_g16: 14 instead of 28 B per texel over PCIe)
+    try:
+        nr = h_n.numpy().reshape(-1, 4); po = h_p.numpy().reshape(-1, 3)
+        n16 = np.empty((npix, 4), np.uint16)
+        n16[:, :3] = np.rint(nr[:, :3].astype(np.float64) * 65535.0).astype(np.uint16)
+        n16[:, 3] = nr[:, 3].astype(np.uint16)
+        h_n16 = torch.from_numpy(n16).pin_memory()
+        h_p16 = torch.from_numpy(po.astype(np.float16).view(np.uint16)).pin_memory()
+        n = 40
+        g.frame_enqueue_host_g16(h_n16, h_p16, W, H, outs[0]); g.frame_finish()
+        ref_img = h_o.clone()
+        g.frame_enqueue_host(h_p, h_n, W, H, h_o); g.frame_finish(); ref_img.copy_(h_o)
+        g.frame_enqueue_host_g16(h_n16, h_p16, W, H, h_o2); g.frame_finish()
+        same = bool(torch.equal(ref_img, h_o2))
+        t0 = time.perf_counter()
+        g.frame_enqueue_host_g16(h_n16, h_p16, W, H, outs[0])
+        for i in range(1, n):
+            g.frame_enqueue_host_g16(h_n16, h_p16, W, H, outs[i & 1])
+            g.frame_finish()
+        g.frame_finish()
+        cfg["ms_per_frame_host_to_host_g16_pipelined"] = round((time.perf_counter() - t0) * 1e3 / n, 3)
+        cfg["host_to_host_g16_note"] = ("rt_hip_frame_enqueue_g16: RGBA16 UNORM normals + RGB16F positions (the rasterizer's FBO formats, ras_rasterizer.cpp:293,301), "
+                                        "%.1f MB up per frame, widened on the device; image identical to the float entry's: %s" % (npix * 14 / 1e6, same))
+        del h_n16, h_p16
+    except Exception as e:
+        cfg["host_to_host_g16_note"] = "not measured: %r" % (e,)
     # one frame at a time, as SURVEY 8d words the GPU timing (3 warm-up + 20 timed, median and p95): call -> image complete,
     # host clock around rt_hip_render_frame_device + stream sync, G-buffer and image resident in HBM
     ts = []
@@ -665,7 +755,7 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
     # north_star's target: ~1M triangles at 1080p, same shading
     target = None
     if args.workload == "atrium-262k-1080p":
-        sc1 = scenes.atrium(1048576)
+        sc1 = atrium_cached(scenes, 1048576)
         g1 = rt.RtHip(sc1, semantics="array", accel=ACCEL[args.accel], device=dev_index, profile=0, bounces=2, do_shadows=1,
                       shadow_t_max=1.0 if args.shadow_mode == "corrected" else 0.0, seed=42)
         b1 = g1.stats()
@@ -682,7 +772,191 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
     return cfg, target
 
 
-def run_cpu_baseline(scene, d_n, d_p, W, H, sample):
+def _strong_share(rt, torch, g, d_p, d_n, w, h, whole_ms, reps=6):
+    """What a strong-scaling split costs, predicted on ONE GPU: for N = 2, 4, 8 every virtual rank shades its interleaved 64x64
+    tiles of the frame into its packed chunk (rt_hip_render_tiles_packed_device, the call rank r of an N-GPU job makes) and the
+    N chunks are unpacked (rt_hip_unpack_chunks_device); the frame time of the job is that of its slowest rank + the unpack
+    (+ the all-gather, which one GPU cannot measure).  Implied efficiency = whole-frame time / (N x that)."""
+    from raytracer_amd.tiles import max_owned_tiles
+    packed = type(g).render_tiles_packed_device.__wrapped__
+    out = {}
+    img = torch.zeros(w * h * 4, dtype=torch.uint8, device=d_p.device)
+    for n in (2, 4, 8):
+        chunk = max_owned_tiles(w, h, 64, n) * 64 * 64 * 4
+        recv = torch.zeros(n * chunk, dtype=torch.uint8, device=d_p.device)
+        per_rank = []
+        for r in range(n):
+            dst = [recv[r * chunk:(r + 1) * chunk]]
+            for _ in range(2):
+                packed(g, [d_p], [d_n], w, h, 64, r, n, dst)
+            g.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                packed(g, [d_p], [d_n], w, h, 64, r, n, dst)
+            g.sync()
+            per_rank.append((time.perf_counter() - t0) / reps * 1e3)
+        unpack = type(g).unpack_chunks_device.__wrapped__
+        unpack(g, recv, chunk, w, h, 64, n, img); g.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            unpack(g, recv, chunk, w, h, 64, n, img)
+        g.sync()
+        un = (time.perf_counter() - t0) / reps * 1e3
+        slow = max(per_rank)
+        out[str(n)] = {"slowest_rank_ms": round(slow, 4), "fastest_rank_ms": round(min(per_rank), 4), "unpack_ms": round(un, 4),
+                       "implied_efficiency": round(whole_ms / (n * (slow + un)), 3), "all_gather_bytes_per_rank": int(chunk)}
+    return out
+
+
+def run_more_configs(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACCEL, whole_ms):
+    """Objects beside the headline line, none of them `value` (all on rank 0 at N = 1, untimed by the driver's metric):
+    reference_equivalent   SURVEY 8d's run: 0.75x prepass (1440x810), interlace 16 -> what ONE reference frame traces, through
+                           RayTracer::processRays' entry with host pointers (rt_hip_process_gbuffer) and device-resident
+    process_rays_full_frame  the same call on every covered texel of the 1080p G-buffer (like-for-like with cpu_baseline)
+    strong_share_ms        the strong-scaling prediction of _strong_share at 1080p (and at 4K under c4_single_gpu_share)
+    c4_single_gpu_share    atrium-1M at 4K: one GPU doing C4's whole frame
+    c5                     atrium-262k + 10 M photons emitted: photon pass, photon-mapped frame, gather figures"""
+    import torch
+    out = {}
+    npix = W * H
+    shadow_t_max = 1.0 if args.shadow_mode == "corrected" else 0.0
+    fp = ctypes.POINTER(ctypes.c_float)
+    # ---- processRays: reference-equivalent sample and the full frame, on a context with RayTracer semantics ----
+    try:
+        g2 = rt.RtHip(scene, accel=ACCEL[args.accel], device=dev_index)      # semantics="raytracer": world space, FLT_EPSILON, t_max = inf
+        pw, ph = int(W * 0.75), int(H * 0.75)                                # prepass_resolution 0.75 (ras_rasterizer.cpp:39,167-168)
+        d_n = torch.zeros(pw * ph * 4, dtype=torch.float32, device=dev)
+        d_p = torch.zeros(pw * ph * 3, dtype=torch.float32, device=dev)
+        g.render_gbuffer_device(scene.fov, pw, ph, d_n, d_p)
+        g.sync()
+        nr = d_n.cpu().numpy().reshape(-1, 4); po = d_p.cpu().numpy().reshape(-1, 3)
+        idx = np.arange(pw * ph)
+        sel = (idx % 16 == 0) & (nr[:, 3] > 0)                               # INTERLACE 16, phase 0, alpha > 0 (ras_rasterizer.cpp:16,509-519)
+        pos = np.ascontiguousarray(po[sel]); nrm = np.ascontiguousarray((nr[sel, :3].astype(np.float64) * 2.0 - 1.0).astype(np.float32))
+
+        def c_call(p_, n_):
+            res_p, off_p, nres, nmat = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(0), ctypes.c_int(0)
+            g2._ck(g2.lib.rt_hip_process_gbuffer(g2.h, p_.ctypes.data_as(fp), n_.ctypes.data_as(fp), p_.shape[0], ctypes.byref(res_p),
+                                                 ctypes.byref(off_p), ctypes.byref(nres), ctypes.byref(nmat)))
+            return nres.value, nmat.value
+
+        def timed(fn, reps):
+            for _ in range(3):
+                r = fn()
+            g2.sync()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter(); r = fn(); g2.sync(); ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts)), r
+
+        ms_host, (hits, groups) = timed(lambda: c_call(pos, nrm), 30)
+        d_pos = torch.from_numpy(pos).to(dev); d_nrm = torch.from_numpy(nrm).to(dev)
+        d_res = torch.zeros(max(pos.shape[0], 1) * 16, dtype=torch.float32, device=dev)
+        d_off = torch.zeros(2 * 4096, dtype=torch.int32, device=dev)
+        dev_call = type(g2).process_gbuffer_device.__wrapped__
+        ms_dev, _ = timed(lambda: dev_call(g2, d_pos, d_nrm, pos.shape[0], d_res, d_off), 30)
+        out["reference_equivalent"] = {
+            "what": "what ONE frame of the reference traces at 1080p: 0.75x prepass (%dx%d), interlace 16 -> %d reflection rays through "
+                    "RayTracer::processRays' entry (ray-gen, closest hit, hit records grouped by material); scene up to date "
+                    "(rt_hip_update finds nothing to do; the reference rebuilds its soup every call)" % (pw, ph, pos.shape[0]),
+            "rays": int(pos.shape[0]), "hit_records": int(hits), "material_groups": int(groups),
+            "gpu_host_pointers_ms": round(ms_host, 4), "gpu_host_pointers_mrays_per_s": round(pos.shape[0] / ms_host / 1e3, 2),
+            "gpu_device_resident_ms": round(ms_dev, 4), "gpu_device_resident_mrays_per_s": round(pos.shape[0] / ms_dev / 1e3, 2),
+            "entry": "rt_hip_process_gbuffer (host pointers in, pinned host records out: PCIe-inclusive) / rt_hip_process_gbuffer_device; median of 30"}
+        out["_ref_equiv_sample"] = (pos, nrm)
+        # the whole 1080p G-buffer through the same call
+        nrf = gb_n.cpu().numpy().reshape(-1, 4); pof = gb_p.cpu().numpy().reshape(-1, 3)
+        self_ = nrf[:, 3] > 0
+        posf = np.ascontiguousarray(pof[self_]); nrmf = np.ascontiguousarray((nrf[self_, :3].astype(np.float64) * 2.0 - 1.0).astype(np.float32))
+        ms_hostf, (hitsf, groupsf) = timed(lambda: c_call(posf, nrmf), 8)
+        d_posf = torch.from_numpy(posf).to(dev); d_nrmf = torch.from_numpy(nrmf).to(dev)
+        d_resf = torch.zeros(posf.shape[0] * 16, dtype=torch.float32, device=dev)
+        ms_devf, _ = timed(lambda: dev_call(g2, d_posf, d_nrmf, posf.shape[0], d_resf, d_off), 15)
+        out["process_rays_full_frame"] = {
+            "what": "RayTracer::processRays' entry on all %d covered texels of the 1080p G-buffer (reflection rays, closest hit, 64-byte hit records "
+                    "grouped by material): the call cpu_baseline times" % posf.shape[0],
+            "rays": int(posf.shape[0]), "hit_records": int(hitsf), "material_groups": int(groupsf),
+            "gpu_device_resident_ms": round(ms_devf, 4), "gpu_device_resident_mrays_per_s": round(posf.shape[0] / ms_devf / 1e3, 1),
+            "gpu_host_pointers_ms": round(ms_hostf, 4), "gpu_host_pointers_mrays_per_s": round(posf.shape[0] / ms_hostf / 1e3, 1),
+            "host_pointers_note": "%.0f MB of positions / normals up, %.0f MB of hit records down per call: PCIe-bound" % (posf.shape[0] * 24 / 1e6, hitsf * 64 / 1e6)}
+        del d_posf, d_nrmf, d_resf, d_pos, d_nrm, d_res
+        g2.close()
+    except Exception as e:   # an extra must not take the line with it
+        out["reference_equivalent_error"] = repr(e)
+    # ---- strong-scaling share at 1080p on the bench context ----
+    try:
+        out["strong_share_ms"] = {"1080p": _strong_share(rt, torch, g, gb_p, gb_n, W, H, whole_ms),
+                                  "whole_frame_ms": round(whole_ms, 4),
+                                  "note": "one GPU playing every rank of an N-GPU strong-scaling job in turn: slowest rank's rt_hip_render_tiles_packed_device "
+                                          "(call -> done, host clock) + rt_hip_unpack_chunks_device; implied_efficiency = whole_frame_ms / (N x (slowest + unpack)); "
+                                          "the RCCL all-gather between the two is not included (all_gather_bytes_per_rank says what it moves)"}
+    except Exception as e:
+        out["strong_share_error"] = repr(e)
+    # ---- C4's single-GPU share: atrium-1M at 4K ----
+    try:
+        if args.workload == "atrium-262k-1080p":
+            sc1 = atrium_cached(scenes, 1048576)
+            g1 = rt.RtHip(sc1, semantics="array", accel=ACCEL[args.accel], device=dev_index, profile=1, bounces=2, do_shadows=1,
+                          shadow_t_max=shadow_t_max, seed=42)
+            w4, h4 = 3840, 2160
+            d_n = torch.zeros(w4 * h4 * 4, dtype=torch.float32, device=dev)
+            d_p = torch.zeros(w4 * h4 * 3, dtype=torch.float32, device=dev)
+            o4 = torch.zeros(w4 * h4 * 4, dtype=torch.uint8, device=dev)
+            g1.render_gbuffer_device(sc1.fov, w4, h4, d_n, d_p)
+            g1.sync(); g1.reset_stats()
+            ms, mr, rpf = timed_frames(g1, d_p, d_n, w4, h4, o4, 40)
+            st1 = g1.stats()
+            out["c4_single_gpu_share"] = {"workload": "atrium-1m-4k", "triangles": sc1.num_tris, "width": w4, "height": h4, "ms_per_frame": round(ms, 4),
+                                          "value": round(mr, 1), "unit": "Mrays/s", "rays_per_frame": int(rpf), "frames": 40,
+                                          "k_shadow_ms_per_launch": round(st1["any_ms"] / max(st1["any_launches"], 1), 4),
+                                          "strong_share_ms": _strong_share(rt, torch, g1, d_p, d_n, w4, h4, ms, reps=3),
+                                          "note": "BASELINE.json configs[3] (C4: ~1M triangles, 4K, reflections + refractions, 8 GPUs) on ONE GPU: the whole frame, and "
+                                                  "under strong_share_ms each of 8 (4, 2) ranks' share of it"}
+            g1.close()
+            del d_n, d_p, o4
+    except Exception as e:
+        out["c4_error"] = repr(e)
+    # ---- C5: the bench scene + 10 M photons ----
+    try:
+        if args.workload == "atrium-262k-1080p":
+            from raytracer_amd.photons import build_photon_map
+            per_light = 2_500_000
+            g5 = rt.RtHip(scene, semantics="array", accel=ACCEL[args.accel], device=dev_index, profile=1, bounces=2, do_shadows=1,
+                          shadow_t_max=shadow_t_max, use_photon_map=1, photon_estimate=100, photon_radius=1.0, seed=42)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            nph = build_photon_map(g5, per_light, len(scene.lights), dev)
+            g5.sync()
+            pass_ms = (time.perf_counter() - t0) * 1e3
+            o5 = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)
+            g5.reset_stats()
+            ms, mr, rpf = timed_frames(g5, gb_p, gb_n, W, H, o5, 12, warm=2)
+            st5 = g5.stats()
+            g5.set_config(census=1, profile=0); g5.reset_stats()
+            g5.render_frame_device(gb_p, gb_n, W, H, o5)
+            cs = g5.stats()
+            launches = max(st5["gather_launches"], 1)
+            visits = cs["census_gather_visits"] / max(cs["gather_launches"], 1)
+            gms = st5["gather_ms"] / launches
+            out["c5"] = {"workload": "atrium-262k-1080p + photons", "photons_emitted": per_light * len(scene.lights), "photons_stored": int(nph),
+                         "photon_pass_ms": round(pass_ms, 3), "ms_per_frame": round(ms, 4), "frames": 12, "photon_estimate": 100, "photon_radius": 1.0,
+                         "gather_ms_per_launch": round(gms, 4), "gather_launches_per_frame": round(launches / 14.0, 2),
+                         "gather_points_per_launch": round(st5["gather_points"] / launches, 1),
+                         "gather_roofline": {"bound": "valu", "achieved": round(visits * GATHER_VISIT_FLOP / (gms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TFLOPS,
+                                             "unit": "TFLOP/s", "frac": round(visits * GATHER_VISIT_FLOP / (gms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                                             "photon_visits_per_launch": round(visits, 1),
+                                             "work_definition": "first pass priced as a plain grid walk (10 FLOP per photon of the coarse cells within the radius); the kernels "
+                                                                "read less (interiors counted from the cell table) and do more (selection, sum)"},
+                         "note": "BASELINE.json configs[4] (C5): photon pass = emit (sharded by index) + grids, once; frames shade with radiance_estimate "
+                                 "(k = 100, r = 1) instead of shadow rays, through the synchronous frame driver"}
+            g5.close()
+            del o5
+    except Exception as e:
+        out["c5_error"] = repr(e)
+    return out
+
+
+def run_cpu_baseline(scene, d_n, d_p, W, H, sample, ref_equiv_sample=None):
     """RayTracer::processRays of the compiled reference (or the oracle port) on a bounded sample."""
     from oracle import pyoracle
     nr = d_n.cpu().numpy().reshape(-1, 4)
@@ -704,6 +978,15 @@ def run_cpu_baseline(scene, d_n, d_p, W, H, sample):
     t0 = time.perf_counter()
     r = cpu.process_rays(po[pick], nrm[pick])
     dt = time.perf_counter() - t0
+    ref_equiv = None
+    if ref_equiv_sample is not None:
+        rp, rn = ref_equiv_sample
+        cpu.process_rays(rp, rn)
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter(); rr = cpu.process_rays(rp, rn); ts.append((time.perf_counter() - t1) * 1e3)
+        ref_equiv = {"ms": round(float(np.median(ts)), 3), "mrays_per_s": round(len(rp) / float(np.median(ts)) / 1e3, 4), "cores": 1, "kind": kind,
+                     "hits": int(len(rr["records"])), "sample": "the same %d samples, the same call (soup rebuild + DACRT + records inside it, as every reference frame pays), median of 3" % len(rp)}
     out = {"value": round(len(pick) / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": kind,
            "sample": "RayTracer::processRays (DACRT, reflection rays, closest hit) on %d of the %d covered 1080p "
                      "G-buffer texels (every %dth), %.1f s, %d hits" % (len(pick), len(sel), stride, dt, len(r["records"]))}
@@ -726,6 +1009,8 @@ def run_cpu_baseline(scene, d_n, d_p, W, H, sample):
                                       "each, %.1f s, %d hits" % (len(pick_mt), cores, dt_mt, sum(hits))}
     except Exception as e:                                # the single-core column stands on its own
         out["all_cores"] = {"error": str(e)}
+    if ref_equiv:
+        out["reference_equivalent"] = ref_equiv
     return out
 
 

@@ -378,6 +378,13 @@ int rt_hip_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays);
  * Frames enqueued through either entry finish in order through the same rt_hip_frame_finish. */
 int rt_hip_frame_enqueue(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float* gbuf_nrm_rgba, int width, int height,
                          uint8_t* rgba_out);
+/* The same with the G-buffer in the formats the rasterizer's FBO holds (ras_rasterizer.cpp:293,301): normals RGBA16 UNORM
+ * (4 x uint16 per texel, the alpha word = material id + 1 as an integer, 0 = empty), positions RGB16F (3 x IEEE half per
+ * texel) -- what the reference widens to floats only in glReadPixels (ras_rasterizer.cpp:497,543).  14 instead of 28 bytes
+ * per texel cross PCIe; c / 65535 and half -> float are applied on the device and are exact, so the frame is bit for bit
+ * the one rt_hip_frame_enqueue renders from the widened planes.  Same buffer lifetime rules, same rt_hip_frame_finish. */
+int rt_hip_frame_enqueue_g16(rt_hip_ctx* ctx, const uint16_t* gbuf_nrm_rgba16, const uint16_t* gbuf_pos_rgb16f, int width, int height,
+                             uint8_t* rgba_out);
 /* Secondary rays issued by the last frame call (shadow + reflection + refraction). */
 int64_t rt_hip_last_frame_rays(rt_hip_ctx* ctx);
 

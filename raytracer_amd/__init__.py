@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device", "rt_hip_gbuffer_select_noalloc_device",
-    "rt_hip_frame_enqueue_device", "rt_hip_frame_enqueue", "rt_hip_frame_finish", "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device",
+    "rt_hip_frame_enqueue_device", "rt_hip_frame_enqueue", "rt_hip_frame_enqueue_g16", "rt_hip_frame_finish", "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device",
     "rt_hip_photon_generate_multi", "rt_hip_set_model_mats", "rt_hip_photon_generate", "rt_hip_photon_get", "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
 ]
 
@@ -151,6 +151,7 @@ def load_library() -> C.CDLL:
     L.rt_hip_render_tiles_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_frame_enqueue_device.argtypes = [P, P, P, C.c_int, C.c_int, P]
     L.rt_hip_frame_enqueue.argtypes = [P, P, P, C.c_int, C.c_int, P]
+    L.rt_hip_frame_enqueue_g16.argtypes = [P, P, P, C.c_int, C.c_int, P]
     L.rt_hip_frame_finish.argtypes = [P, C.POINTER(C.c_int64)]
     L.rt_hip_last_frame_rays.argtypes = [P]
     L.rt_hip_last_frame_rays.restype = C.c_int64
@@ -470,6 +471,12 @@ class RtHip:
         until frame_finish() has returned for this frame."""
         ptr = lambda a: C.c_void_p(a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data)
         self._ck(self.lib.rt_hip_frame_enqueue(self.h, ptr(h_pos_rgb), ptr(h_nrm_rgba), w, h, ptr(h_rgba)))
+
+    def frame_enqueue_host_g16(self, h_nrm_rgba16, h_pos_rgb16f, w, h, h_rgba):
+        """rt_hip_frame_enqueue_g16: the same pipeline fed with the G-buffer in its native 16-bit formats (uint16 x 4 UNORM
+        normals with alpha = material id + 1, IEEE half x 3 positions as uint16 / float16 arrays)."""
+        ptr = lambda a: C.c_void_p(a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data)
+        self._ck(self.lib.rt_hip_frame_enqueue_g16(self.h, ptr(h_nrm_rgba16), ptr(h_pos_rgb16f), w, h, ptr(h_rgba)))
 
     def frame_enqueue_device(self, d_pos_rgb, d_nrm_rgba, w, h, d_rgba):
         """Queue a whole frame without waiting for it (at most two unfinished); frame_finish() completes the oldest."""

@@ -134,7 +134,7 @@ int rt_hip_comm_destroy(rt_hip_ctx* ctx)
 
 // One frame split over the ranks of the context's communicator (strong scaling): this rank shades its interleaved
 // tiles straight into its packed chunk, one all-gather hands every rank all chunks, one kernel scatters them into
-// the image.  With a one-rank communicator the same steps run (whole frame -> pack -> all-gather of one -> unpack).
+// the image.  A one-rank communicator runs exactly the same steps (packed tiles -> all-gather of one chunk -> unpack).
 int rt_hip_render_frame_multi_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
                                      int height, int tile, uint8_t* d_rgba_out)
 {
@@ -158,18 +158,7 @@ int rt_hip_render_frame_multi_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rg
 	}
 	uint8_t* send = ctx->d_mg_send.as<uint8_t>();
 	int64_t rays = 0;
-	if (nranks == 1) {
-		RT_CHECK(rt_render_frame(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, tile, 0, 1, d_rgba_out));
-		rays = ctx->last_frame_rays;
-		const int ntiles = ((width + tile - 1) / tile) * ((height + tile - 1) / tile);
-		std::vector<int> ids(ntiles);
-		for (int i = 0; i < ntiles; ++i) ids[i] = i;
-		RT_CHECK(ctx->d_tile_list.reserve((size_t)ntiles * sizeof(int)));
-		RT_HIP_CHECK(hipMemcpyAsync(ctx->d_tile_list.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, st));
-		RT_HIP_CHECK(hipStreamSynchronize(st));  // ids dies here
-		memset(ctx->tile_key, 0, sizeof(ctx->tile_key));  // d_tile_list no longer holds the cached owned-tile list
-		RT_CHECK(rt_launch_tiles_pack(ctx, true, d_rgba_out, width, height, tile, ctx->d_tile_list.as<int>(), ntiles, send));
-	} else {
+	{	// every communicator size takes this one path (a single rank owns all the tiles)
 		const float* pos[1] = {d_gbuf_pos_rgb};
 		const float* nrm[1] = {d_gbuf_nrm_rgba};
 		uint8_t* out[1] = {send};

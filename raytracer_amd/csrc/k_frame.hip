@@ -333,6 +333,23 @@ __global__ __launch_bounds__(BLOCK) void k_select_scatter(const float* __restric
 	if (index_out) index_out[d] = i;
 }
 
+// ---- the G-buffer in its native 16-bit formats (ras_rasterizer.cpp:293,301) --------------------------
+// What glReadPixels(GL_FLOAT) does on the way out of the GL (ras_rasterizer.cpp:497,543), on this side of PCIe:
+// UNORM16 -> c / 65535 and half -> float, both exact, so the float planes are the ones the float entries take.
+// The alpha word carries material id + 1 as an integer (this build's G-buffer convention; the reference's is 0 / 1).
+__global__ __launch_bounds__(BLOCK) void k_decode_g16(const ushort4* __restrict__ nrm16, const uint16_t* __restrict__ pos16, int n,
+                                                      float4* __restrict__ nrm_rgba, float* __restrict__ pos_rgb)
+{
+	const int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const ushort4 q = nrm16[i];
+	nrm_rgba[i] = make_float4((float)q.x / 65535.0f, (float)q.y / 65535.0f, (float)q.z / 65535.0f, (float)q.w);
+	for (int k = 0; k < 3; ++k) {
+		__half_raw hr; hr.x = pos16[3 * (size_t)i + k];
+		pos_rgb[3 * (size_t)i + k] = __half2float(__half(hr));
+	}
+}
+
 // ---- software G-buffer (primary rays) -----------------------------------------------------------
 __device__ __forceinline__ float unorm16(float c)
 {
@@ -1325,12 +1342,12 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	const int packed = fs.packed;
 	fs.tile_list = nullptr; fs.ntiles = 0; fs.packed = 0;
 	fs.per_frame = tile8_count(w, h);
-	if (nranks > 1 && tile % 8 == 0) {
+	if ((nranks > 1 || packed) && tile % 8 == 0) {   // (a one-rank communicator takes the same path: it owns every tile)
 		RT_CHECK(owned_tile_list(ctx, w, h, tile, rank, nranks, &fs.tile_list, &fs.ntiles));
 		fs.per_frame = fs.ntiles * tile * tile;
 		fs.packed = packed;
 	}
-	if (packed && !fs.packed) { rt_set_error("packed tile output needs nranks > 1 and a tile size that is a multiple of 8"); return RT_HIP_ERR_ARG; }
+	if (packed && !fs.packed) { rt_set_error("packed tile output needs a tile size that is a multiple of 8"); return RT_HIP_ERR_ARG; }
 	if ((int64_t)fs.per_frame * fs.nframes > FRAME_LEVEL_CAP) return RT_HIP_OK;
 	const int n0 = fs.per_frame * fs.nframes;
 	pf->n0 = n0; pf->bounces = bounces; pf->nframes = fs.nframes; pf->num_lights = sv.num_lights; pf->rays = 0;
@@ -1762,6 +1779,15 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 // rt_hip_frame_enqueue_device queues a whole frame and returns without waiting for it; rt_hip_frame_finish waits for the
 // OLDEST enqueued frame and accounts for it.  With one frame enqueued ahead, the host's per-frame work (reading the
 // counters, returning to the caller, queueing the next dozen launches: ~55 us) runs under the previous frame's kernels.
+int rt_launch_decode_g16(rt_hip_ctx* ctx, const uint16_t* d_nrm16, const uint16_t* d_pos16, int n, float* d_nrm_rgba, float* d_pos_rgb)
+{
+	if (n <= 0) return RT_HIP_OK;
+	hipLaunchKernelGGL(k_decode_g16, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, (const ushort4*)d_nrm16, d_pos16, n,
+	                   (float4*)d_nrm_rgba, d_pos_rgb);
+	RT_HIP_CHECK(hipGetLastError());
+	return RT_HIP_OK;
+}
+
 int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba)
 {
 	if (ctx->pending_count >= 2) { rt_set_error("two frames are already enqueued: rt_hip_frame_finish() one first"); return RT_HIP_ERR_STATE; }

@@ -404,7 +404,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 		if (ctx->pending[k].ev1) (void)hipEventDestroy(ctx->pending[k].ev1);
 		for (hipEvent_t e : {ctx->pending[k].ev_up, ctx->pending[k].ev_done, ctx->pending[k].ev_down})
 			if (e) (void)hipEventDestroy(e);
-		ctx->d_pipe_pos[k].release(); ctx->d_pipe_nrm[k].release(); ctx->d_pipe_img[k].release();
+		ctx->d_pipe_pos[k].release(); ctx->d_pipe_nrm[k].release(); ctx->d_pipe_img[k].release(); ctx->d_pipe_g16[k].release();
 	}
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -953,6 +953,46 @@ int rt_hip_frame_enqueue(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float
 	RT_HIP_CHECK(hipMemcpyAsync(ctx->d_pipe_nrm[slot].p, gbuf_nrm_rgba, npix * 16, hipMemcpyHostToDevice, ctx->up_stream));
 	RT_HIP_CHECK(hipEventRecord(pf->ev_up, ctx->up_stream));
 	RT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, pf->ev_up, 0));
+	RT_CHECK(rt_frame_enqueue(ctx, ctx->d_pipe_pos[slot].as<float>(), ctx->d_pipe_nrm[slot].as<float>(), width, height,
+	                          ctx->d_pipe_img[slot].as<uint8_t>()));
+	RT_HIP_CHECK(hipEventRecord(pf->ev_done, ctx->stream));
+	RT_HIP_CHECK(hipStreamWaitEvent(ctx->down_stream, pf->ev_done, 0));
+	RT_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_pipe_img[slot].p, npix * 4, hipMemcpyDeviceToHost, ctx->down_stream));
+	RT_HIP_CHECK(hipEventRecord(pf->ev_down, ctx->down_stream));
+	pf->host = true;
+	pf->h_rgba = rgba_out;
+	pf->img_bytes = npix * 4;
+	return RT_HIP_OK;
+}
+
+// rt_hip_frame_enqueue with the G-buffer in the formats the rasterizer's FBO holds it in (RGBA16 UNORM normals,
+// RGB16F positions: ras_rasterizer.cpp:293,301) instead of the floats glReadPixels widens them to (:497,543): half the
+// bytes over PCIe (14 instead of 28 per texel), decoded on the device (exact), same frame bit for bit.
+int rt_hip_frame_enqueue_g16(rt_hip_ctx* ctx, const uint16_t* gbuf_nrm_rgba16, const uint16_t* gbuf_pos_rgb16f, int width, int height,
+                             uint8_t* rgba_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !gbuf_nrm_rgba16 || !gbuf_pos_rgb16f || !rgba_out) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	if (ctx->pending_count >= 2) { rt_set_error("two frames are already enqueued: rt_hip_frame_finish() one first"); return RT_HIP_ERR_STATE; }
+	const int slot = (ctx->pending_head + ctx->pending_count) & 1;
+	PendingFrame* pf = &ctx->pending[slot];
+	if (!ctx->up_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+	if (!ctx->down_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+	if (!pf->ev_up) RT_HIP_CHECK(hipEventCreateWithFlags(&pf->ev_up, hipEventDisableTiming));
+	if (!pf->ev_done) RT_HIP_CHECK(hipEventCreateWithFlags(&pf->ev_done, hipEventDisableTiming));
+	if (!pf->ev_down) RT_HIP_CHECK(hipEventCreateWithFlags(&pf->ev_down, hipEventDisableTiming));
+	const size_t npix = (size_t)width * height;
+	RT_CHECK(ctx->d_pipe_g16[slot].reserve(npix * 14));
+	RT_CHECK(ctx->d_pipe_pos[slot].reserve(npix * 12));
+	RT_CHECK(ctx->d_pipe_nrm[slot].reserve(npix * 16));
+	RT_CHECK(ctx->d_pipe_img[slot].reserve(npix * 4));
+	uint16_t* d_n16 = ctx->d_pipe_g16[slot].as<uint16_t>();
+	uint16_t* d_p16 = d_n16 + npix * 4;
+	RT_HIP_CHECK(hipMemcpyAsync(d_n16, gbuf_nrm_rgba16, npix * 8, hipMemcpyHostToDevice, ctx->up_stream));
+	RT_HIP_CHECK(hipMemcpyAsync(d_p16, gbuf_pos_rgb16f, npix * 6, hipMemcpyHostToDevice, ctx->up_stream));
+	RT_HIP_CHECK(hipEventRecord(pf->ev_up, ctx->up_stream));
+	RT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, pf->ev_up, 0));
+	RT_CHECK(rt_launch_decode_g16(ctx, d_n16, d_p16, (int)npix, ctx->d_pipe_nrm[slot].as<float>(), ctx->d_pipe_pos[slot].as<float>()));
 	RT_CHECK(rt_frame_enqueue(ctx, ctx->d_pipe_pos[slot].as<float>(), ctx->d_pipe_nrm[slot].as<float>(), width, height,
 	                          ctx->d_pipe_img[slot].as<uint8_t>()));
 	RT_HIP_CHECK(hipEventRecord(pf->ev_done, ctx->stream));

@@ -138,6 +138,7 @@ struct rt_hip_ctx {
 	void* h_pipe = nullptr;                                       // pinned: 2 x 512 B of frame counters
 	hipStream_t up_stream = nullptr, down_stream = nullptr;       // rt_hip_frame_enqueue: G-buffer up / image down beside the frame's stream
 	DevBuf d_pipe_pos[2], d_pipe_nrm[2], d_pipe_img[2];           // its device staging, one set per pending slot
+	DevBuf d_pipe_g16[2];                                         // rt_hip_frame_enqueue_g16: the 14 B / texel planes as they crossed PCIe
 	DevBuf d_census, d_spill, d_tile_list;
 	int tile_key[5] = {0, 0, 0, 0, 0};                            // (w, h, tile, rank, nranks) of d_tile_list
 	int tile_count = 0;
@@ -265,6 +266,7 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
                     int rank, int nranks, uint8_t* d_rgba);
 int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba);
 int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays);
+int rt_launch_decode_g16(rt_hip_ctx* ctx, const uint16_t* d_nrm16, const uint16_t* d_pos16, int n, float* d_nrm_rgba, float* d_pos_rgb);
 int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
                      int h, int tile, int rank, int nranks, uint8_t* const* d_rgba, int packed = 0);
 int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int w, int h, int tile, int nranks,

@@ -40,6 +40,13 @@ if vals.get("TCC_REQ_sum"):
     out["l2_hit_frac"] = round(vals.get("TCC_HIT_sum", 0.0) / vals["TCC_REQ_sum"], 4)
 if vals.get("TCP_TOTAL_CACHE_ACCESSES_sum") and "TCP_TCC_READ_REQ_sum" in vals:
     out["l1_hit_frac"] = round(1.0 - vals["TCP_TCC_READ_REQ_sum"] / vals["TCP_TOTAL_CACHE_ACCESSES_sum"], 4)
+# Cache-level request bytes per launch (north_star: "achieved L2 GB/s for traversal node fetches against peak"): requests x line size.
+# TCC_REQ counts L2 requests of up to one 128-byte line; TCP_TOTAL_CACHE_ACCESSES counts the L1's tag look-ups, 64 bytes each (one
+# quarter-wave of a 16 B/lane load).  Both are upper bounds on the bytes that moved (a request may ask for less than a line).
+if vals.get("TCC_REQ_sum"):
+    out["l2_request_bytes_per_launch"] = vals["TCC_REQ_sum"] * 128.0
+if vals.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+    out["l1_request_bytes_per_launch"] = vals["TCP_TOTAL_CACHE_ACCESSES_sum"] * 64.0
 if vals.get("SQ_WAVE_CYCLES"):
     out["wait_any_frac"] = round(vals.get("SQ_WAIT_ANY", 0.0) / vals["SQ_WAVE_CYCLES"], 4)
 json.dump(out, open(out_path, "w"), indent=1)

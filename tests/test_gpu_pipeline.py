@@ -104,3 +104,43 @@ def test_host_pipeline_equals_host_frames():
     assert g.frame_finish() == exp[1][1] and np.array_equal(plain, exp[1][0])
     del pos_copy, nrm_copy
     g.close()
+
+
+def test_g16_pipeline_is_bit_identical_to_the_float_entry():
+    """rt_hip_frame_enqueue_g16: the G-buffer in the FBO's own formats (RGBA16 UNORM normals, RGB16F positions:
+    ras_rasterizer.cpp:293,301), widened on the device the way glReadPixels(GL_FLOAT) widens it (:497,543) -- c / 65535
+    and half -> float, both exact.  The 16-bit planes here are made from the float G-buffer, the round trip is checked to
+    be lossless on the host first, and the frames must equal rt_hip_render_frame's on the float planes bit for bit."""
+    import torch
+    import raytracer_amd as rt
+    sc = scenes.atrium(8192)
+    g = rt.RtHip(sc, semantics="array", accel=rt.ACCEL_PLOC, bounces=2, do_shadows=1, shadow_t_max=1.0)
+    w, h = 320, 200
+    frames = []
+    for f in range(3):
+        d_n = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+        d_p = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+        g.render_gbuffer_device(sc.fov - 0.05 * f, w, h, d_n, d_p)
+        g.sync()
+        nr, po = d_n.cpu().numpy().reshape(-1, 4), d_p.cpu().numpy().reshape(-1, 3)
+        n16 = np.empty((w * h, 4), np.uint16)
+        n16[:, :3] = np.rint(nr[:, :3].astype(np.float64) * 65535.0).astype(np.uint16)
+        n16[:, 3] = nr[:, 3].astype(np.uint16)                      # material id + 1
+        p16 = po.astype(np.float16)
+        # the 16-bit planes hold the G-buffer exactly (it was quantised to these formats when it was made)
+        assert np.array_equal((n16[:, :3].astype(np.float32) / np.float32(65535.0)).view(np.uint32), nr[:, :3].view(np.uint32))
+        assert np.array_equal(p16.astype(np.float32).view(np.uint32), po.view(np.uint32))
+        img = g.render_frame(po, nr, w, h)
+        frames.append((torch.from_numpy(n16).pin_memory(), torch.from_numpy(p16.view(np.uint16)).pin_memory(),
+                       np.asarray(img).reshape(-1).copy(), g.last_frame_rays()))
+    outs = [torch.full((w * h * 4,), 7, dtype=torch.uint8).pin_memory() for _ in range(3)]
+    g.frame_enqueue_host_g16(frames[0][0], frames[0][1], w, h, outs[0])
+    g.frame_enqueue_host_g16(frames[1][0], frames[1][1], w, h, outs[1])
+    rays = [g.frame_finish()]
+    g.frame_enqueue_host_g16(frames[2][0], frames[2][1], w, h, outs[2])
+    rays += [g.frame_finish(), g.frame_finish()]
+    assert rays == [f[3] for f in frames]
+    for k in range(3):
+        assert np.array_equal(outs[k].numpy(), frames[k][2]), "frame %d" % k
+    assert int(outs[0].numpy().reshape(-1, 4)[:, :3].max()) > 40
+    g.close()
