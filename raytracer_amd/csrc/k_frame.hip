@@ -537,7 +537,7 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
 		const f3 I = active ? normalized3(P) : mk3(0, 0, 0);
 		NodeGeo g;
 		st3(g.V, P); st3(g.N, N);
-		st3(inc + 3 * (size_t)j, I);
+		if (inc) st3(inc + 3 * (size_t)j, I);  // (the sync-free driver passes nullptr: level 0's incident direction is normalize(V), recomputed where it is needed)
 		// where k_combine writes this node's pixel: frame f's image, or (packed) the rank's chunk of frame f
 		g.parent = i < 0 ? -1 : (fs.packed ? f * fs.per_frame + slot : f * (w * h) + i);
 		g.material = mat;
@@ -727,7 +727,9 @@ __global__ __launch_bounds__(CBLOCK) void k_spawn_refract(SceneView sv, const No
 			if (m.alpha > 0.1f) {
 				const NodeGeo g = geo[i];
 				V = ld3(g.V);
-				f3 N = ld3(g.N), I = ld3(inc + 3 * (size_t)i);
+				// inc == nullptr: level 0, whose incident direction is normalize(V) (the eye is the origin) -- the same arithmetic
+				// as the stored copy, 12 bytes per node the level-0 pass no longer writes
+				f3 N = ld3(g.N), I = inc ? ld3(inc + 3 * (size_t)i) : normalized3(V);
 				float IoR = m.ior;
 				float idn = dot3(I, N);
 				T = div3(I - N * idn, IoR);
@@ -781,7 +783,8 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
                                                          int* __restrict__ child_count, int child_capacity,
                                                          int* __restrict__ overflow, const Hit* __restrict__ tc_hits,
                                                          float* __restrict__ child_uv,
-                                                         unsigned int* __restrict__ parent_flags)
+                                                         unsigned int* __restrict__ parent_flags,
+                                                         NodeShade* __restrict__ parent_shade)
 {
 	nq = dev_count(nq, n_ptr);
 	int i = blockIdx.x * CBLOCK + threadIdx.x;
@@ -809,19 +812,51 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
 		child_geo[slot] = g;
 		if (child_occl) child_occl[slot] = 0u;
 		if (parent_flags) atomicOr(&parent_flags[parent], branch == 0 ? CHILD_REFL_BIT : CHILD_REFR_BIT);
+		// where the child sits in its level, for a parent that fetches the child's colour itself (k_combine, pull form);
+		// valid exactly where the flag above is set, like the colour slots of this record
+		if (parent_shade) { if (branch == 0) parent_shade[parent].pad1 = __int_as_float(slot); else parent_shade[parent].pad2 = __int_as_float(slot); }
 		if (child_uv) { child_uv[2 * (size_t)slot] = tc[0]; child_uv[2 * (size_t)slot + 1] = tc[1]; }
 	}
 }
 
 // Bottom-up combine of one level: color = (shadow*light) * ((kd*diff + ref*refc) + alpha*refrc)
 // (rt_raytracer.cpp:158).  Level 0 writes RGBA8 as renderScene does (rt_raytracer.cpp:175-185).
+// The colour shade() returns for one node, given what its children returned.
+__device__ __forceinline__ f3 node_colour(const SceneView& sv, const NodeGeo& g, f3 F, f3 refc, f3 refrc, const float* __restrict__ node_uv,
+                                          size_t i, bool lit, unsigned int oc)
+{
+	const MaterialRec m = sv.materials[g.material];
+	float ref = m.reflectivity, alpha = m.alpha;
+	float kd = (float)(1.0 - (double)ref - (double)alpha);
+	f3 diff = ld3(m.diffuse);
+	if (node_uv) {  // textured scenes only: diff_color = texture->lookup(texcoord) (rt_raytracer.cpp:93-95)
+		const TexRec t = sv.tex[g.material];
+		if (t.w > 0) diff = tex_lookup_ref(t, sv.texels, node_uv[2 * i], node_uv[2 * i + 1]);
+	}
+	f3 mix = (diff * kd + refc * ref) + refrc * alpha;
+	if (lit) {  // deferred light_color(): the level's shadow rays have landed by now
+		float f = light_factor(sv, ld3(g.V), ld3(g.N), oc);
+		F = mk3(f, f, f);
+	}
+	return mk3(F.x * mix.x, F.y * mix.y, F.z * mix.z);
+}
+
+// The children one level down, when that level is the LAST one (its nodes have no children and nobody else needs their
+// colours): this level's combine fetches and shades them itself (`pull`), so the last level needs no launch of its own
+// and no colour is written to and read back from NodeShade.  Same expressions on the same operands: same bits.
+struct ChildLevel {
+	const NodeGeo* geo;          // nullptr: children pushed their colours into shade[] (a launch per level)
+	const unsigned int* occl;
+	const float* uv;
+};
+
 __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* __restrict__ geo,
                                                    const NodeShade* __restrict__ shade, int n,
                                                    const int* __restrict__ n_ptr, int level,
                                                    NodeShade* __restrict__ parent_shade, FrameSet fs, int frame_pixels,
                                                    float* __restrict__ rgb_float, int lit,
                                                    const unsigned int* __restrict__ occl,
-                                                   const float* __restrict__ node_uv)
+                                                   const float* __restrict__ node_uv, ChildLevel pull)
 {
 	n = dev_count(n, n_ptr);
 	int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -830,30 +865,32 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 	if (g.material == -2) return;
 	f3 col = mk3(0, 0, 0);
 	if (g.material >= 0) {
-		const MaterialRec m = sv.materials[g.material];
 		NodeShade s;
 		const unsigned int oc = (lit && occl) ? occl[i] : 0u;
 		if (lit) {  // sync-free driver: a child's colour exists only where the flag says so
 			st3(s.F, mk3(0, 0, 0));
-			st3(s.refc, (oc & CHILD_REFL_BIT) ? ld3(shade[i].refc) : mk3(0, 0, 0));
-			st3(s.refrc, (oc & CHILD_REFR_BIT) ? ld3(shade[i].refrc) : mk3(0, 0, 0));
+			if (pull.geo) {
+				const f3 zero = mk3(0, 0, 0);
+				f3 rc = zero, rr = zero;
+				if (oc & CHILD_REFL_BIT) {
+					const size_t c = (size_t)__float_as_int(shade[i].pad1);
+					const NodeGeo cg = pull.geo[c];
+					rc = node_colour(sv, cg, zero, zero, zero, pull.uv, c, true, pull.occl[c]);
+				}
+				if (oc & CHILD_REFR_BIT) {
+					const size_t c = (size_t)__float_as_int(shade[i].pad2);
+					const NodeGeo cg = pull.geo[c];
+					rr = node_colour(sv, cg, zero, zero, zero, pull.uv, c, true, pull.occl[c]);
+				}
+				st3(s.refc, rc); st3(s.refrc, rr);
+			} else {
+				st3(s.refc, (oc & CHILD_REFL_BIT) ? ld3(shade[i].refc) : mk3(0, 0, 0));
+				st3(s.refrc, (oc & CHILD_REFR_BIT) ? ld3(shade[i].refrc) : mk3(0, 0, 0));
+			}
 		} else {
 			s = shade[i];
 		}
-		float ref = m.reflectivity, alpha = m.alpha;
-		float kd = (float)(1.0 - (double)ref - (double)alpha);
-		f3 diff = ld3(m.diffuse);
-		if (node_uv) {  // textured scenes only: diff_color = texture->lookup(texcoord) (rt_raytracer.cpp:93-95)
-			const TexRec t = sv.tex[g.material];
-			if (t.w > 0) diff = tex_lookup_ref(t, sv.texels, node_uv[2 * (size_t)i], node_uv[2 * (size_t)i + 1]);
-		}
-		f3 mix = (diff * kd + ld3(s.refc) * ref) + ld3(s.refrc) * alpha;
-		f3 F = ld3(s.F);
-		if (lit) {  // deferred light_color(): the level's shadow rays have landed by now
-			float f = light_factor(sv, ld3(g.V), ld3(g.N), oc);
-			F = mk3(f, f, f);
-		}
-		col = mk3(F.x * mix.x, F.y * mix.y, F.z * mix.z);
+		col = node_colour(sv, g, ld3(s.F), ld3(s.refc), ld3(s.refrc), node_uv, (size_t)i, lit != 0, oc);
 	}
 	if (level > 0) {
 		float* dst = node_branch(g) == 0 ? parent_shade[node_parent(g)].refc : parent_shade[node_parent(g)].refrc;
@@ -1432,7 +1469,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		if (L == 0) {
 			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
 			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, fs, w, h, n0,
-			                   tile, rank, nranks, recurse ? 1 : 0, geo, inc_base, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
+			                   tile, rank, nranks, recurse ? 1 : 0, geo, (float*)nullptr, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
 		} else if (recurse) {
 			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created.  The last
 			// level needs nothing here: no rays to spawn, the light term is k_combine's, NodeShade stays unwritten.
@@ -1463,26 +1500,34 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		const Hit* tc_hits = (sv.num_spheres > 0 && sv.num_tris == 0) ? nullptr : ctx->d_hits.as<Hit>();
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
 		                   lc + 1, 0, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
-		                   level_uv(L + 1), occl);
+		                   level_uv(L + 1), occl, shade);
 		// refraction, gated after the reflection hits are known (Q9)
 		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo,
-		                   (const float*)(inc_base + 3 * (size_t)off[L]), n, n_ptr, gate, q_org, q_dir, q_parent, lc + 2);
+		                   L == 0 ? (const float*)nullptr : (const float*)(inc_base + 3 * (size_t)off[L]), n, n_ptr, gate, q_org, q_dir, q_parent, lc + 2);
 		RT_HIP_CHECK(hipGetLastError());
 		if (fuse) RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2));
 		else RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
 		                   lc + 2, 1, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
-		                   level_uv(L + 1), occl);
+		                   level_uv(L + 1), occl, shade);
 		RT_HIP_CHECK(hipGetLastError());
 	}
-	for (int L = bounces - 1; L >= 0; --L) {
+	// The last level is folded into the combine of the level above it (pull form: a launch, a 5 us gap and a round trip of
+	// the children's colours through NodeShade less); deeper frames chain the remaining levels bottom-up as before.
+	for (int L = bounces >= 2 ? bounces - 2 : 0; L >= 0; --L) {
 		const int* n_ptr = L == 0 ? nullptr : fc + 8 + 8 * L;
 		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + off[L];
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + off[L - 1] : nullptr;
 		const unsigned int* occl = ctx->d_occ.as<unsigned int>() + off[L];
+		ChildLevel pull = {nullptr, nullptr, nullptr};
+		if (bounces >= 2 && L == bounces - 2) {
+			pull.geo = ctx->d_nodes_a.as<NodeGeo>() + off[L + 1];
+			pull.occl = ctx->d_occ.as<unsigned int>() + off[L + 1];
+			pull.uv = level_uv(L + 1);
+		}
 		hipLaunchKernelGGL(k_combine, dim3(nblocks((int)cap[L], BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, (int)cap[L], n_ptr, L,
-		                   pshade, fs, fs.packed ? fs.per_frame : w * h, (float*)nullptr, 1, occl, level_uv(L));
+		                   pshade, fs, fs.packed ? fs.per_frame : w * h, (float*)nullptr, 1, occl, level_uv(L), pull);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_HIP_CHECK(hipMemcpyAsync(pf->h_fc, fc, (size_t)nfc * 4, hipMemcpyDeviceToHost, st));  // 512 B pinned per slot; nfc <= 80 ints
@@ -1726,7 +1771,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
 			                   q_parent, nq, (const int*)nullptr, 0, gate, child_geo, level_inc(geo_off[L + 1]), (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
-			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr);
+			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr, (NodeShade*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 		}
 		// refraction, gated after the reflection hits are known (Q9)
@@ -1743,7 +1788,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
 			                   q_parent, nq, (const int*)nullptr, 1, gate, child_geo, level_inc(geo_off[L + 1]), (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
-			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr);
+			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr, (NodeShade*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
 			RT_HIP_CHECK(hipStreamSynchronize(st));
@@ -1759,7 +1804,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + geo_off[L];
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + geo_off[L - 1] : nullptr;
 		hipLaunchKernelGGL(k_combine, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, (const int*)nullptr, L,
-		                   pshade, fs1, w * h, (float*)nullptr, 0, (const unsigned int*)nullptr, level_uv(geo_off[L]));
+		                   pshade, fs1, w * h, (float*)nullptr, 0, (const unsigned int*)nullptr, level_uv(geo_off[L]), ChildLevel{nullptr, nullptr, nullptr});
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));
