@@ -784,7 +784,7 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
                                                          int* __restrict__ overflow, const Hit* __restrict__ tc_hits,
                                                          float* __restrict__ child_uv,
                                                          unsigned int* __restrict__ parent_flags,
-                                                         NodeShade* __restrict__ parent_shade)
+                                                         int* __restrict__ parent_child_slot)
 {
 	nq = dev_count(nq, n_ptr);
 	int i = blockIdx.x * CBLOCK + threadIdx.x;
@@ -814,7 +814,8 @@ __global__ __launch_bounds__(CBLOCK) void k_make_children(SceneView sv, const Hi
 		if (parent_flags) atomicOr(&parent_flags[parent], branch == 0 ? CHILD_REFL_BIT : CHILD_REFR_BIT);
 		// where the child sits in its level, for a parent that fetches the child's colour itself (k_combine, pull form);
 		// valid exactly where the flag above is set, like the colour slots of this record
-		if (parent_shade) { if (branch == 0) parent_shade[parent].pad1 = __int_as_float(slot); else parent_shade[parent].pad2 = __int_as_float(slot); }
+		// (an array of its own, two ints per node: the parents of consecutive queue entries ascend, so these writes share lines)
+		if (parent_child_slot) parent_child_slot[2 * (size_t)parent + branch] = slot;
 		if (child_uv) { child_uv[2 * (size_t)slot] = tc[0]; child_uv[2 * (size_t)slot + 1] = tc[1]; }
 	}
 }
@@ -848,6 +849,7 @@ struct ChildLevel {
 	const NodeGeo* geo;          // nullptr: children pushed their colours into shade[] (a launch per level)
 	const unsigned int* occl;
 	const float* uv;
+	const int* slot;             // [node][branch] -> the child's index in its level (valid where the node's child flag is set)
 };
 
 __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* __restrict__ geo,
@@ -873,12 +875,12 @@ __global__ __launch_bounds__(BLOCK) void k_combine(SceneView sv, const NodeGeo* 
 				const f3 zero = mk3(0, 0, 0);
 				f3 rc = zero, rr = zero;
 				if (oc & CHILD_REFL_BIT) {
-					const size_t c = (size_t)__float_as_int(shade[i].pad1);
+					const size_t c = (size_t)pull.slot[2 * (size_t)i];
 					const NodeGeo cg = pull.geo[c];
 					rc = node_colour(sv, cg, zero, zero, zero, pull.uv, c, true, pull.occl[c]);
 				}
 				if (oc & CHILD_REFR_BIT) {
-					const size_t c = (size_t)__float_as_int(shade[i].pad2);
+					const size_t c = (size_t)pull.slot[2 * (size_t)i + 1];
 					const NodeGeo cg = pull.geo[c];
 					rr = node_colour(sv, cg, zero, zero, zero, pull.uv, c, true, pull.occl[c]);
 				}
@@ -1427,6 +1429,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	// light term needs all shadow rays of the level, so it is evaluated in k_combine at the end.
 	const bool fuse = shadows && !(sv.num_spheres > 0 && sv.num_tris == 0);
 	RT_CHECK(ctx->d_occ.reserve((size_t)off[bounces] * 4));  // shadow masks and child flags
+	RT_CHECK(ctx->d_child_slot.reserve((size_t)off[bounces] * 8));  // [node][branch] -> child index (k_combine's pull form)
 	auto shadow_launch = [&](const NodeGeo* geo, int n, const int* n_ptr, int lo, int hi, unsigned int* occl,
 	                         const int* q_count) -> int {
 		FusedQueue fq{};
@@ -1500,7 +1503,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		const Hit* tc_hits = (sv.num_spheres > 0 && sv.num_tris == 0) ? nullptr : ctx->d_hits.as<Hit>();
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
 		                   lc + 1, 0, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
-		                   level_uv(L + 1), occl, shade);
+		                   level_uv(L + 1), occl, ctx->d_child_slot.as<int>() + 2 * off[L]);
 		// refraction, gated after the reflection hits are known (Q9)
 		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo,
 		                   L == 0 ? (const float*)nullptr : (const float*)(inc_base + 3 * (size_t)off[L]), n, n_ptr, gate, q_org, q_dir, q_parent, lc + 2);
@@ -1509,7 +1512,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		else RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
 		                   lc + 2, 1, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
-		                   level_uv(L + 1), occl, shade);
+		                   level_uv(L + 1), occl, ctx->d_child_slot.as<int>() + 2 * off[L]);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	// The last level is folded into the combine of the level above it (pull form: a launch, a 5 us gap and a round trip of
@@ -1520,8 +1523,9 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + off[L - 1] : nullptr;
 		const unsigned int* occl = ctx->d_occ.as<unsigned int>() + off[L];
-		ChildLevel pull = {nullptr, nullptr, nullptr};
+		ChildLevel pull = {nullptr, nullptr, nullptr, nullptr};
 		if (bounces >= 2 && L == bounces - 2) {
+			pull.slot = ctx->d_child_slot.as<int>() + 2 * off[L];
 			pull.geo = ctx->d_nodes_a.as<NodeGeo>() + off[L + 1];
 			pull.occl = ctx->d_occ.as<unsigned int>() + off[L + 1];
 			pull.uv = level_uv(L + 1);
@@ -1771,7 +1775,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
 			                   q_parent, nq, (const int*)nullptr, 0, gate, child_geo, level_inc(geo_off[L + 1]), (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
-			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr, (NodeShade*)nullptr);
+			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr, (int*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 		}
 		// refraction, gated after the reflection hits are known (Q9)
@@ -1788,7 +1792,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			tc_hits = spheres ? nullptr : ctx->d_hits.as<Hit>();
 			hipLaunchKernelGGL(k_make_children, dim3(nblocks(nq, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, (const Hit*)nullptr, q_dir,
 			                   q_parent, nq, (const int*)nullptr, 1, gate, child_geo, level_inc(geo_off[L + 1]), (unsigned int*)nullptr, qcount + 1, 0x7fffffff,
-			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr, (NodeShade*)nullptr);
+			                   qcount + 2, tc_hits, level_uv(geo_off[L + 1]), (unsigned int*)nullptr, (int*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_HIP_CHECK(hipMemcpyAsync(h_counts, qcount, 16, hipMemcpyDeviceToHost, st));
 			RT_HIP_CHECK(hipStreamSynchronize(st));
@@ -1804,7 +1808,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + geo_off[L];
 		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + geo_off[L - 1] : nullptr;
 		hipLaunchKernelGGL(k_combine, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, n, (const int*)nullptr, L,
-		                   pshade, fs1, w * h, (float*)nullptr, 0, (const unsigned int*)nullptr, level_uv(geo_off[L]), ChildLevel{nullptr, nullptr, nullptr});
+		                   pshade, fs1, w * h, (float*)nullptr, 0, (const unsigned int*)nullptr, level_uv(geo_off[L]), ChildLevel{nullptr, nullptr, nullptr, nullptr});
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_HIP_CHECK(hipEventRecord(ctx->ev1, st));

@@ -388,7 +388,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
 	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list, &ctx->d_all_tiles,
-	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_fcount, &ctx->d_leaf_order, &ctx->d_photon_emit, &ctx->d_level_nodes,
+	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_child_slot, &ctx->d_fcount, &ctx->d_leaf_order, &ctx->d_photon_emit, &ctx->d_level_nodes,
 	                  &ctx->d_mg_send, &ctx->d_mg_recv, &ctx->d_mg_counts, &ctx->d_mg_photons,
 	                  &ctx->d_photons_f, &ctx->d_photon_sorted_f, &ctx->d_cell_start_f};
 	for (DevBuf* b : bufs) b->release();
