@@ -68,6 +68,59 @@ __device__ __forceinline__ void grid_for_each(const SceneView& sv, int64_t total
 	for (int64_t i = xcd_block_index(sv.xcd_chunk) * blockDim.x + threadIdx.x; i < total; i += gsize) body(i);
 }
 
+// Control state of a traversal lives in `cur` alone: a node (>= 0, the byte offset of its QNode), a leaf (< 0, ~byte offset
+// of its TriIsect) or one of three sentinels.  A lane that hits (any-hit) or runs out of stack leaves through the loop
+// condition `cur < RT_CUR_POP`; "pop" is a value of cur, not a flag.  Flags (`found`, `pop`) and a `break` in the body make
+// the compiler carry exit masks through every divergent region and merge them each iteration: that was a third of the
+// loop's scalar instructions (0.323 -> 0.290 ms per k_shadow launch on the 1080p frame without them).  The bottom stack
+// entry is EXIT, so a pop needs no empty-stack test.
+#define RT_CUR_EXIT 0x7fffffff
+#define RT_CUR_HIT 0x7ffffffe
+#define RT_CUR_POP 0x7ffffffd
+
+// One iteration for a lane with cur < RT_CUR_POP: it visits either an internal node or a leaf ("if-if").  Measured
+// against "while-while" (inner loop over internal nodes, leaves batched per wave) on MI355X: 0.563 ms vs 0.681 ms for the
+// shadow rays of atrium-262k -- on 64-wide waves the lanes parked at a leaf cost more than the masked triangle code does
+// (round 3, leaves run only when >= 4 / 8 / 16 lanes wait at one: 0.275 / 0.303 / 0.322 against 0.252 ms).
+template <bool ANY, bool CENSUS>
+__device__ __forceinline__ void bvh_step(const SceneView& sv, const RayPre& rp, f3 O, f3 D, Hit& best, int& cur, lds_int*& top,
+                                         lds_int* lim, int stride, uint32_t& cnt_nodes, uint32_t& cnt_tris)
+{
+	if (cur >= 0) {
+		const uint4* np = (const uint4*)((const char*)sv.qnodes + (uint32_t)cur);
+		const uint4 w0 = np[0], w1 = np[1];
+		const int2 ch = make_int2((int)w1.z, (int)w1.w);
+		if (CENSUS) ++cnt_nodes;
+		float tl, tr;
+		bool hl, hr;
+		slab2(rp, w0, w1, ANY ? sv.tp.t_max : best.t, hl, hr, tl, tr);
+		// right child first iff it is hit and (the left one is not, or the right one is entered earlier): one compare
+		// of the entry distances with +inf standing for "not hit" -- no branch, no mask arithmetic
+		const float inf = __builtin_inff();
+		const bool right_first = (hr ? tr : inf) < (hl ? tl : inf);
+		if (hl && hr) {
+			stack_push(sv, top, lim, stride, right_first ? ch.x : ch.y);
+			top += stride;
+		}
+		cur = (hl || hr) ? (right_first ? ch.y : ch.x) : RT_CUR_POP;
+	} else {
+		const TriIsect* tp = (const TriIsect*)((const char*)sv.tris + (uint32_t)(~cur));
+		float4 a = tp->a, b = tp->b, c = tp->c;
+		// keep the three loads together: left alone, the compiler sinks the load of `a` below
+		// the det test and the leaf visit pays two memory round trips instead of one
+		asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+		if (CENSUS) ++cnt_tris;
+		f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+		if (ANY) {
+			cur = mt_any(O, D, v0, e1, e2, sv.tp) ? RT_CUR_HIT : RT_CUR_POP;
+		} else {
+			mt_closest(O, D, v0, e1, e2, __float_as_uint(a.w), sv.tp, best);
+			cur = RT_CUR_POP;
+		}
+	}
+	if (cur == RT_CUR_POP) { top -= stride; cur = stack_pop(sv, top, lim, stride); }
+}
+
 template <bool ANY, bool CENSUS>
 __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& best, lds_int* stack, int stride,
                                           uint32_t& cnt_nodes, uint32_t& cnt_tris)
@@ -79,59 +132,13 @@ __device__ __forceinline__ bool bvh_trace(const SceneView& sv, f3 O, f3 D, Hit& 
 	bool found = false;
 	if (sv.num_tris > 0) {
 		const RayPre rp = ray_pre(sv.qframe, O, D);
-		// One loop, node or leaf per iteration ("if-if").  Measured against "while-while" (inner loop
-		// over internal nodes, leaves batched per wave) on MI355X: 0.563 ms vs 0.681 ms for the shadow
-		// rays of atrium-262k -- on 64-wide waves the lanes parked at a leaf cost more than the masked
-		// triangle code does.
 		// num_tris == 1: no internal node; the root "node" is leaf slot 0.
-		// Control state lives in `cur` alone: a node (>= 0), a leaf (~slot < 0) or one of three sentinels.  A lane that
-		// hits (any-hit) or runs out of stack leaves through the loop condition; "pop" is a value of cur, not a flag.
-		// Flags (`found`, `pop`) and a `break` in the body make the compiler carry exit masks through every divergent
-		// region and merge them each iteration: that was a third of the loop's scalar instructions (0.323 -> 0.290 ms
-		// per k_shadow launch on the 1080p frame without them).  The bottom stack entry is EXIT, so a pop needs no
-		// empty-stack test.
-		const int EXIT = 0x7fffffff, HIT = 0x7ffffffe, POP = 0x7ffffffd;
 		int cur = (sv.num_tris == 1) ? ~0 : 0;
 		lds_int* const lim = stack + sv.lds_depth * stride;
-		stack_push(sv, stack, lim, stride, EXIT);
+		stack_push(sv, stack, lim, stride, RT_CUR_EXIT);
 		lds_int* top = stack + stride;
-		while (cur < POP) {
-			if (cur >= 0) {
-				// cur = byte offset of the node (k_lbvh.hip: qnode_ref)
-				const uint4* np = (const uint4*)((const char*)sv.qnodes + (uint32_t)cur);
-				const uint4 w0 = np[0], w1 = np[1];
-				const int2 ch = make_int2((int)w1.z, (int)w1.w);
-				if (CENSUS) ++cnt_nodes;
-				float tl, tr;
-				bool hl, hr;
-				slab2(rp, w0, w1, ANY ? sv.tp.t_max : best.t, hl, hr, tl, tr);
-				// right child first iff it is hit and (the left one is not, or the right one is entered earlier): one compare
-				// of the entry distances with +inf standing for "not hit" -- no branch, no mask arithmetic
-				const float inf = __builtin_inff();
-				const bool right_first = (hr ? tr : inf) < (hl ? tl : inf);
-				if (hl && hr) {
-					stack_push(sv, top, lim, stride, right_first ? ch.x : ch.y);
-					top += stride;
-				}
-				cur = (hl || hr) ? (right_first ? ch.y : ch.x) : POP;
-			} else {
-				const TriIsect* tp = (const TriIsect*)((const char*)sv.tris + (uint32_t)(~cur));
-				float4 a = tp->a, b = tp->b, c = tp->c;
-				// keep the three loads together: left alone, the compiler sinks the load of `a` below
-				// the det test and the leaf visit pays two memory round trips instead of one
-				asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
-				if (CENSUS) ++cnt_tris;
-				f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
-				if (ANY) {
-					cur = mt_any(O, D, v0, e1, e2, sv.tp) ? HIT : POP;
-				} else {
-					mt_closest(O, D, v0, e1, e2, __float_as_uint(a.w), sv.tp, best);
-					cur = POP;
-				}
-			}
-			if (cur == POP) { top -= stride; cur = stack_pop(sv, top, lim, stride); }
-		}
-		found = ANY ? (cur == HIT) : (best.prim != RT_MISS);
+		while (cur < RT_CUR_POP) bvh_step<ANY, CENSUS>(sv, rp, O, D, best, cur, top, lim, stride, cnt_nodes, cnt_tris);
+		found = ANY ? (cur == RT_CUR_HIT) : (best.prim != RT_MISS);
 	}
 	if (!ANY && best.prim == RT_MISS) best.t = __builtin_inff();
 	return found;
