@@ -459,14 +459,23 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
     gat_ms, gat_launches, gat_points = st["gather_ms"], st["gather_launches"], st["gather_points"]
     frame_ms = st["frame_ms"]
     # census pass: same frame(s), counting node visits / triangle tests per ray and photons per gather (untimed)
-    g.set_config(census=1, profile=0)
-    g.reset_stats()
-    if strong and world > 1:
-        g.render_tiles_device(gb_p[0], gb_n[0], W, H, 64, rank, world, tiles[0])
-    else:
-        g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
-    cs = g.stats()
-    g.set_config(census=0, profile=1)
+    # The algorithmic work per ray is that of a ray traced by itself from the root: the census runs with the shadow rays' shared descent
+    # (tuning.shadow_prefix) switched off; what the kernels execute with it on is reported beside it.
+    def census_pass():
+        g.set_config(census=1, profile=0)
+        g.reset_stats()
+        if strong and world > 1:
+            g.render_tiles_device(gb_p[0], gb_n[0], W, H, 64, rank, world, tiles[0])
+        else:
+            g.render_tiles_batch_device(gb_p, gb_n, W, H, 64, rank, world, tiles)
+        c = g.stats()
+        g.set_config(census=0, profile=1)
+        return c
+    tun = g.tuning()
+    cs_exec = census_pass()
+    g.set_tuning(shadow_prefix=0)
+    cs = census_pass()
+    g.set_tuning(shadow_prefix=tun["shadow_prefix"])
     nodes_any = cs["census_nodes_any"] / max(cs["census_rays_any"], 1)
     tris_any = cs["census_tris_any"] / max(cs["census_rays_any"], 1)
     nodes_clo = cs["census_nodes_closest"] / max(cs["census_rays_closest"], 1)
@@ -531,7 +540,13 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
                 "nodes_per_ray": round(nodes_dom, 2), "tris_per_ray": round(tris_dom, 2),
                 "kernel_mrays_per_s": round(rays_per_launch / sec / 1e6, 1) if avg_ms > 0 else 0.0,
                 "work_definition": "34 FLOP per BVH node visit (both child boxes: 12 FMA + 8 min/max + 2 compares) + 45 per triangle test "
-                                   "(SURVEY.md 8d), visits and tests counted on the device by a census pass over the identical frame",
+                                   "(SURVEY.md 8d), visits and tests counted on the device by a census pass over the identical frame with every ray "
+                                   "traced from the root by itself (tuning.shadow_prefix = 0): the algorithm's work per ray.  The timed kernels share "
+                                   "the top of the descent between the 64 shadow rays of an 8x8 tile (k_shadow_prefix, its time included in "
+                                   "avg_launch_ms) and execute any_hit_nodes_per_ray_executed visits per ray",
+                "any_hit_nodes_per_ray_executed": round(cs_exec["census_nodes_any"] / max(cs_exec["census_rays_any"], 1), 2),
+                "any_hit_tris_per_ray_executed": round(cs_exec["census_tris_any"] / max(cs_exec["census_rays_any"], 1), 2),
+                "shadow_prefix": tun["shadow_prefix"], "shadow_prefix_steps": tun["shadow_prefix_steps"],
                 "frac_unpacked_peak": round(achieved / VALU_UNPACKED_TFLOPS, 4), "peak_unpacked": VALU_UNPACKED_TFLOPS,
                 "algorithmic_cache_GBs_32B_nodes": round(rays_per_launch * bpr32 / sec / 1e9, 1) if avg_ms > 0 else 0.0,
                 "algorithmic_cache_GBs_64B_nodes": round(rays_per_launch * bpr64 / sec / 1e9, 1) if avg_ms > 0 else 0.0,

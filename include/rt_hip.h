@@ -156,7 +156,15 @@ typedef struct rt_hip_tuning {
 	uint32_t gather_medium;   /* 4096 RT_HIP_GATHER_MEDIUM: first pass of the wave-per-point gather: a point whose coarse cube holds at most this many
 	                                 photons reads them all from the coarse grid; above it the fine grid's cells inside the sphere are counted from
 	                                 the cell table and only the boundary shell is read; 0 = always the shell walk */
-	int reserved[2];
+	int shadow_prefix;        /* 12   RT_HIP_SHADOW_PREFIX: the descent that the 64 shadow rays of a wave share (from the root to the neighbourhood of
+	                                 their origins) is made once per (group of 64 frame nodes, light) and the rays start below it; the value is the
+	                                 most sibling subtrees such a start may put on the rays' stacks (<= 30); 0 = every ray descends from the root */
+	int shadow_prefix_steps;  /* 24   RT_HIP_SHADOW_PREFIX_STEPS: nodes such a shared descent may visit (one lane walks it, the kernel that makes
+	                                 them is as long as its longest walk) */
+	int shadow_prefix_min_rays; /* -1  RT_HIP_SHADOW_PREFIX_MIN_RAYS: level-0 shadow rays (nodes x lights) from which the shared descent is used; -1 = six
+	                                 times the device's resident threads (below that the shadow launches are as long as their slowest wave and the
+	                                 walks cost more than they save); 0 = always */
+	int reserved[3];
 } rt_hip_tuning;
 
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent

@@ -503,17 +503,85 @@ __device__ __forceinline__ int level0_pixel(const FrameSet& fs, int jj, int w, i
 	return (x < w && y < h) ? y * w + x : -1;
 }
 
+// ---- the shared descent of a wave's shadow rays ---------------------------------------------------------
+// The 64 shadow rays of a wave start on neighbouring texels (one 8x8 tile at level 0) and aim at one light.  Every ray
+// starts ON a surface, hence inside every ancestor box of the leaves around its origin: measured on the 1080p frame
+// (profiles/r3_variants/k_shadow.md), the first 17 of a wave's 37 traversal iterations visit the SAME node in all 64
+// lanes -- the descent from the root to the neighbourhood of the origins, 64 times the same box tests.  That descent is
+// made once per (8x8 tile of level 0, light) by ONE lane of a small kernel, against the group as a whole:
+//   * the group's origins and direction vectors are bounded by boxes (k_init_spawn, group_box_store);
+//   * from the root down, while one child box holds all origins: step into that child, and keep its sibling unless
+//     NO ray of the group can cross the sibling's box (interval form of the slab test: every origin in the origin box,
+//     every direction in the direction box -- a superset of the group's rays);
+//   * the record = where the descent stopped (entry) + the kept siblings in stack order.
+// k_shadow then starts each ray of the group at `entry` with the siblings already on its stack.  The traversal only ever
+// visits MORE than the per-ray descent would (a sibling is dropped only when it is missed by every ray), so the any-hit
+// result of every ray is what it was (tests: frames bit-identical with tuning.shadow_prefix = 0 and > 0).
+struct GroupBox {  // 48 B; omin[0] > omax[0]: the group has no active node
+	float omin[3], omax[3];  // origins O = V + 0.1 N
+	float vmin[3], vmax[3];  // node positions V (direction = light - V)
+};
+constexpr int PREFIX_INTS = 32;             // record: [0] siblings kept, [1] entry reference, [2 ..] the siblings, bottom of the stack first
+constexpr int PREFIX_MAX = PREFIX_INTS - 2;
+
+// min / max over the wave through DPP (six vector instructions per value, no LDS traffic: __shfl_xor is a ds_bpermute
+// each, and twelve reductions of them made k_init_spawn 14 us longer); the result is valid in lane 63.
+// quad swaps and the two mirrors leave every lane of a row of 16 with the row's value (min / max are idempotent), then
+// lane 15 of a row is broadcast into the next row (rows 1, 3) and lane 31 into rows 2, 3.
+#define RT_DPP(v, ctrl, row_mask) __builtin_amdgcn_update_dpp(v, v, ctrl, row_mask, 0xf, false)
+__device__ __forceinline__ float wave_min_to_lane63(float x)
+{
+	int v = __float_as_int(x);
+	v = __float_as_int(fminf(__int_as_float(v), __int_as_float(RT_DPP(v, 0xB1, 0xf))));   // quad_perm [1,0,3,2]
+	v = __float_as_int(fminf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x4E, 0xf))));   // quad_perm [2,3,0,1]
+	v = __float_as_int(fminf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x141, 0xf))));  // row_half_mirror
+	v = __float_as_int(fminf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x140, 0xf))));  // row_mirror
+	v = __float_as_int(fminf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x142, 0xa))));  // row_bcast:15 into rows 1 and 3
+	v = __float_as_int(fminf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x143, 0xc))));  // row_bcast:31 into rows 2 and 3
+	return __int_as_float(v);
+}
+__device__ __forceinline__ float wave_max_to_lane63(float x)
+{
+	int v = __float_as_int(x);
+	v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(RT_DPP(v, 0xB1, 0xf))));
+	v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x4E, 0xf))));
+	v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x141, 0xf))));
+	v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x140, 0xf))));
+	v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x142, 0xa))));
+	v = __float_as_int(fmaxf(__int_as_float(v), __int_as_float(RT_DPP(v, 0x143, 0xc))));
+	return __int_as_float(v);
+}
+#undef RT_DPP
+
+// Bounds of the wave's 64 nodes (inactive lanes contribute nothing); lane 63 of the wave stores them.
+__device__ __forceinline__ void group_box_store(bool active, f3 V, f3 N, GroupBox* __restrict__ dst)
+{
+	const float inf = __builtin_inff();
+	float lo[6] = {inf, inf, inf, inf, inf, inf}, hi[6] = {-inf, -inf, -inf, -inf, -inf, -inf};
+	if (active) {
+		const f3 O = V + N * 0.1f;  // as k_shadow forms it
+		lo[0] = hi[0] = O.x; lo[1] = hi[1] = O.y; lo[2] = hi[2] = O.z;
+		lo[3] = hi[3] = V.x; lo[4] = hi[4] = V.y; lo[5] = hi[5] = V.z;
+	}
+	for (int k = 0; k < 6; ++k) { lo[k] = wave_min_to_lane63(lo[k]); hi[k] = wave_max_to_lane63(hi[k]); }
+	if ((threadIdx.x & 63) == 63) {
+		GroupBox b;
+		for (int k = 0; k < 3; ++k) { b.omin[k] = lo[k]; b.omax[k] = hi[k]; b.vmin[k] = lo[3 + k]; b.vmax[k] = hi[3 + k]; }
+		*dst = b;
+	}
+}
+
 __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs, int w, int h, int n0, int tile,
                                                       int rank, int nranks, int recurse, NodeGeo* __restrict__ geo,
                                                       float* __restrict__ inc, int* __restrict__ gate,
                                                       unsigned int* __restrict__ occl, float* __restrict__ q_org,
                                                       float* __restrict__ q_dir, int* __restrict__ q_parent,
                                                       int* __restrict__ q_count, int* __restrict__ active_count,
-                                                      float* __restrict__ node_uv)
+                                                      float* __restrict__ node_uv, GroupBox* __restrict__ group_boxes)
 {
 	int j = blockIdx.x * CBLOCK + threadIdx.x;
 	bool active = false, emit = false;
-	f3 P = mk3(0, 0, 0), R = mk3(0, 0, 0);
+	f3 P = mk3(0, 0, 0), R = mk3(0, 0, 0), Nrm = mk3(0, 0, 0);
 	if (j < n0) {
 		const int f = j / fs.per_frame;
 		int slot;
@@ -534,6 +602,7 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
 			N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
 		}
 		active = mat >= 0;
+		Nrm = N;
 		const f3 I = active ? normalized3(P) : mk3(0, 0, 0);
 		NodeGeo g;
 		st3(g.V, P); st3(g.N, N);
@@ -555,6 +624,7 @@ __global__ __launch_bounds__(CBLOCK) void k_init_spawn(SceneView sv, FrameSet fs
 			emit = true;
 		}
 	}
+	if (group_boxes && (j & ~63) < n0) group_box_store(active, P, Nrm, group_boxes + (j >> 6));  // (the shared descent of the shadow rays)
 	// two compactions share the workgroup's barriers: active count and reflection queue
 	__shared__ int s_cnt;
 	if (threadIdx.x == 0) s_cnt = 0;
@@ -584,13 +654,160 @@ struct FusedQueue {
 	unsigned long long* census;
 };
 
+// One lane per (light, group).  Record (light * ngroups + group), ngroups = ceil(n / 64): where k_shadow's item
+// light * 64 * ngroups + node looks for it.
+__global__ __launch_bounds__(BLOCK) void k_shadow_prefix(SceneView sv, const GroupBox* __restrict__ boxes, int n,
+                                                         const int* __restrict__ n_ptr, int nlights, float shadow_t_max,
+                                                         int max_push, int max_steps, int* __restrict__ prefix)
+{
+	__shared__ int s_stack[PREFIX_MAX][BLOCK];  // the group's stack while it is traced: [entry][lane], conflict-free
+	n = dev_count(n, n_ptr);
+	const int ngroups = (n + 63) >> 6;
+	const int64_t id = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+	if (id >= (int64_t)ngroups * nlights) return;
+	const int light = (int)(id / ngroups), grp = (int)(id - (int64_t)light * ngroups);
+	int* rec = prefix + id * PREFIX_INTS;
+	int cur = (sv.num_tris == 1) ? ~0 : 0, cnt = 0;
+	const GroupBox b = boxes[grp];
+	if (!(b.omin[0] <= b.omax[0])) { rec[0] = 0; rec[1] = cur; return; }
+	const float t_max = shadow_t_max > 0.0f ? shadow_t_max : sv.tp.t_max;
+	// Per axis, mirrored so that every direction component is positive: origin in [o0, o1], direction in [d0, d1] with
+	// d0 > 0 (float subtraction is monotone, so light - vmax <= light - V <= light - vmin holds for the rounded values the
+	// rays use), r0 = 1 / d0 >= r1 = 1 / d1.  With the box's entry plane at A * q + Ce and its exit plane at A * q + Cx
+	// (q = the plane's 16-bit index; the planes pushed outward by two grid cells and by the rounding of the decode), the
+	// rays of the group reach the entry plane no earlier than min(e r0, e r1), e = A q + Ce - o1, and so on: each bound is
+	// two FMAs of q with per-lane constants, widened by `err`, the rounding bound of such an FMA (cancellation included).
+	// An axis on which the directions change sign (`open`) bounds nothing unless the origins lie inside the slab.
+	struct AxisPre {
+		float a0, a1;          // A r0, A r1
+		float el0, el1;        // (Ce - o1) r0 - err, (Ce - o1) r1 - err : lower bound of t_entry
+		float eh0, eh1;        // (Ce - o0) r0 + err, ...                : upper bound of t_entry
+		float xl0, xl1;        // (Cx - o1) ...                          : lower bound of t_exit
+		float xh0, xh1;        // (Cx - o0) ...                          : upper bound of t_exit
+		int she, shx;          // which half-word of the plane pair is the entry / exit plane
+	} ax[3];
+	bool open[3];
+	float blo_pad[3], bhi_pad[3];
+	const float* Lp = sv.lights[light].position;
+	for (int k = 0; k < 3; ++k) {
+		const float pad = 2.0f * sv.qframe.scale[k] + 1e-6f * sv.qframe.reach[k];
+		blo_pad[k] = sv.qframe.org[k] - pad; bhi_pad[k] = sv.qframe.org[k] + pad;
+		float d0 = Lp[k] - b.vmax[k], d1 = Lp[k] - b.vmin[k];
+		open[k] = !(d0 > 0.0f || d1 < 0.0f);
+		const bool neg = d1 < 0.0f;
+		float o0 = b.omin[k], o1 = b.omax[k];
+		if (neg) { const float t = -d0; d0 = -d1; d1 = t; o0 = -b.omax[k]; o1 = -b.omin[k]; }
+		const float r0 = 1.0f / d0, r1 = 1.0f / d1;
+		const float A = neg ? -sv.qframe.scale[k] : sv.qframe.scale[k];
+		const float Ce = (neg ? -sv.qframe.org[k] : sv.qframe.org[k]) - pad, Cx = (neg ? -sv.qframe.org[k] : sv.qframe.org[k]) + pad;
+		const float err = 1e-6f * (sv.qframe.reach[k] + pad + fmaxf(fabsf(o0), fabsf(o1))) * r0;
+		AxisPre& p = ax[k];
+		p.a0 = A * r0; p.a1 = A * r1;
+		p.el0 = (Ce - o1) * r0 - err; p.el1 = (Ce - o1) * r1 - err;
+		p.eh0 = (Ce - o0) * r0 + err; p.eh1 = (Ce - o0) * r1 + err;
+		p.xl0 = (Cx - o1) * r0 - err; p.xl1 = (Cx - o1) * r1 - err;
+		p.xh0 = (Cx - o0) * r0 + err; p.xh1 = (Cx - o0) * r1 + err;
+		p.she = neg ? 16 : 0; p.shx = neg ? 0 : 16;
+	}
+	// The group is traced like one ray (nearer child first, the other on the stack, pop when both are missed) for as long
+	// as every decision is the same for all of its rays: a child box is MISSED by all (dropped -- the only decision results
+	// depend on), HIT by all, or MIXED.  The walk steps into a child only when all rays hit it, may leave a MIXED child on
+	// the stack beside such a step (the rays that miss it spend one visit there), and stops where it would have to step
+	// into a MIXED box, at a leaf, or when the record is full.
+	enum { MISSED = 0, MIXED = 1, ALL = 2 };
+	uint32_t all_mask = 0;  // bit k: stack entry k is hit by all rays
+	// The walk is one chain of dependent node fetches per lane, and the kernel is as long as its longest chain: both
+	// children of a node are requested as soon as the node has arrived (the next node is one of them unless the walk
+	// pops), so a step's fetch runs under the previous step's arithmetic.
+	uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, l0 = w0, l1 = w0, q0 = w0, q1 = w0;
+	if (cur >= 0) { const uint4* np = (const uint4*)((const char*)sv.qnodes + (uint32_t)cur); w0 = np[0]; w1 = np[1]; }
+	for (int step = 0; step < max_steps && cur >= 0; ++step) {
+		const int ref[2] = {(int)w1.z, (int)w1.w};
+		if (ref[0] >= 0) { const uint4* cp = (const uint4*)((const char*)sv.qnodes + (uint32_t)ref[0]); l0 = cp[0]; l1 = cp[1]; }
+		if (ref[1] >= 0) { const uint4* cp = (const uint4*)((const char*)sv.qnodes + (uint32_t)ref[1]); q0 = cp[0]; q1 = cp[1]; }
+		const uint32_t pl[2][3] = {{w0.x, w0.y, w0.z}, {w0.w, w1.x, w1.y}};
+		int cls[2];
+		float key[2];
+		for (int c = 0; c < 2; ++c) {
+			float tn_lb = 0.0f, tn_ub = 0.0f, tf_lb = t_max, tf_ub = t_max;
+			for (int k = 0; k < 3; ++k) {
+				if (open[k]) {
+					// directions of both signs: inside the slab every ray has t_entry <= 0 <= t_exit on this axis; otherwise nothing is known
+					const float blo = __builtin_fmaf((float)(pl[c][k] & 0xffffu), sv.qframe.scale[k], blo_pad[k]);
+					const float bhi = __builtin_fmaf((float)(pl[c][k] >> 16), sv.qframe.scale[k], bhi_pad[k]);
+					const bool inside = b.omin[k] >= blo && b.omax[k] <= bhi;
+					if (!inside) tn_ub = __builtin_inff();
+					tf_lb = inside ? fminf(tf_lb, 0.0f) : -__builtin_inff();
+					continue;
+				}
+				const AxisPre& p = ax[k];
+				const float qe = (float)((pl[c][k] >> p.she) & 0xffffu), qx = (float)((pl[c][k] >> p.shx) & 0xffffu);
+				tn_lb = fmaxf(tn_lb, fminf(__builtin_fmaf(qe, p.a0, p.el0), __builtin_fmaf(qe, p.a1, p.el1)));
+				tn_ub = fmaxf(tn_ub, fmaxf(__builtin_fmaf(qe, p.a0, p.eh0), __builtin_fmaf(qe, p.a1, p.eh1)));
+				tf_lb = fminf(tf_lb, fminf(__builtin_fmaf(qx, p.a0, p.xl0), __builtin_fmaf(qx, p.a1, p.xl1)));
+				tf_ub = fminf(tf_ub, fmaxf(__builtin_fmaf(qx, p.a0, p.xh0), __builtin_fmaf(qx, p.a1, p.xh1)));
+			}
+			const bool missed = tn_lb - 1e-5f * fabsf(tn_lb) > tf_ub + 1e-5f * fabsf(tf_ub);
+			const bool all = tn_ub + 1e-5f * fabsf(tn_ub) <= tf_lb - 1e-5f * fabsf(tf_lb);
+			cls[c] = missed ? MISSED : (all ? ALL : MIXED);
+			key[c] = tn_lb;
+		}
+		if (cls[0] == MISSED && cls[1] == MISSED) {  // pop
+			if (cnt == 0) { cur = RT_CUR_EXIT; break; }  // nothing left: no ray of the group is occluded
+			--cnt;
+			cur = s_stack[cnt][threadIdx.x];
+			if (!((all_mask >> cnt) & 1u) || cur < 0) break;  // a MIXED subtree: the rays decide for themselves from here
+			const uint4* np = (const uint4*)((const char*)sv.qnodes + (uint32_t)cur);
+			w0 = np[0]; w1 = np[1];
+			continue;
+		}
+		const int first = (cls[1] == ALL && (cls[0] != ALL || key[1] < key[0])) ? 1 : 0;
+		if (cls[first] != ALL) break;                  // no child that all rays enter: this node is where they start
+		const int other = first ^ 1;
+		if (cls[other] != MISSED) {
+			if (cnt >= max_push) break;
+			s_stack[cnt][threadIdx.x] = ref[other];
+			all_mask = (all_mask & ~(1u << cnt)) | ((cls[other] == ALL ? 1u : 0u) << cnt);
+			++cnt;
+		}
+		cur = ref[first];
+		w0 = first ? q0 : l0; w1 = first ? q1 : l1;
+	}
+	for (int k = 0; k < cnt; ++k) rec[2 + k] = s_stack[k][threadIdx.x];
+	rec[0] = cnt; rec[1] = cur;
+}
+
+static_assert(TRACE_BLOCK == 64, "a shadow wave = one group of 64 consecutive nodes");
+// Any-hit traversal that starts where the group's shared descent stopped.  `rv`: lane k holds word k of the group's
+// record (loaded by all 64 lanes of the wave).
+template <bool CENSUS>
+__device__ __forceinline__ bool bvh_trace_any_from(const SceneView& sv, f3 O, f3 D, int rv, lds_int* stack, uint32_t& cnt_nodes,
+                                                   uint32_t& cnt_tris)
+{
+	const RayPre rp = ray_pre(sv.qframe, O, D);
+	lds_int* const lim = stack + sv.lds_depth * TRACE_BLOCK;
+	stack_push(sv, stack, lim, TRACE_BLOCK, RT_CUR_EXIT);
+	lds_int* top = stack + TRACE_BLOCK;
+	const int cnt = __builtin_amdgcn_readlane(rv, 0);
+	int cur = __builtin_amdgcn_readlane(rv, 1);
+	for (int k = 0; k < cnt; ++k) {
+		stack_push(sv, top, lim, TRACE_BLOCK, __builtin_amdgcn_readlane(rv, 2 + k));
+		top += TRACE_BLOCK;
+	}
+	Hit best;
+	best.t = sv.tp.t_max;
+	while (cur < RT_CUR_POP) bvh_step<true, CENSUS>(sv, rp, O, D, best, cur, top, lim, TRACE_BLOCK, cnt_nodes, cnt_tris);
+	return cur == RT_CUR_HIT;
+}
+
 // waves_per_eu(8): left alone the kernel takes 74 VGPRs = 6 waves/SIMD; held to 64 (two spills, both
 // outside the traversal loops) it runs at the full 8 and the launch measured 0.351 instead of 0.360 ms.
 template <bool CENSUS>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shadow(SceneView sv, const NodeGeo* __restrict__ geo, int n,
                                                         const int* __restrict__ n_ptr, int light_lo, int light_hi,
                                                         float shadow_t_max, unsigned int* __restrict__ occl,
-                                                        unsigned long long* census, FusedQueue fq)
+                                                        unsigned long long* census, FusedQueue fq,
+                                                        const int* __restrict__ prefix)
 {
 	n = dev_count(n, n_ptr);
 	extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -611,8 +828,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 	}
 	if (shadow_t_max > 0.0f) sv.tp.t_max = shadow_t_max;
 	uint32_t cn = 0, ct = 0, rays = 0;
-	grid_for_each(sv, (int64_t)n * (light_hi - light_lo), [&](int64_t idx) {
-		int light = light_lo + (int)(idx / n), i = (int)(idx % n);
+	// with the shared descent (prefix != nullptr) a light's items are padded to whole groups of 64 nodes, so that a wave
+	// never holds rays of two lights: item = light * npad + node
+	const int npad = prefix ? (n + 63) & ~63 : n;
+	grid_for_each(sv, (int64_t)npad * (light_hi - light_lo), [&](int64_t idx) {
+		int light = light_lo + (int)(idx / npad), i = (int)(idx % npad);
+		int rv = 0;
+		if (prefix) {  // every lane of the wave is here (npad and the grid step are multiples of 64): lane k fetches word k
+			const int64_t group = ((int64_t)light_lo * npad + idx) >> 6;
+			rv = prefix[group * PREFIX_INTS + (threadIdx.x & (PREFIX_INTS - 1))];
+			if (i >= n) return;
+		}
 		const NodeGeo g = geo[i];
 		if (g.material < 0) return;
 		++rays;
@@ -628,7 +854,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 		} else if (sv.use_bvh) {
 			Hit best;
 			uint32_t a = 0, b = 0;
-			blocked = bvh_trace<true, CENSUS>(sv, O, L, best, stack, TRACE_BLOCK, a, b);
+			if (prefix) blocked = bvh_trace_any_from<CENSUS>(sv, O, L, rv, stack, a, b);
+			else blocked = bvh_trace<true, CENSUS>(sv, O, L, best, stack, TRACE_BLOCK, a, b);
 			cn += a; ct += b;
 		} else {
 			Hit best;
@@ -1430,8 +1657,36 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	const bool fuse = shadows && !(sv.num_spheres > 0 && sv.num_tris == 0);
 	RT_CHECK(ctx->d_occ.reserve((size_t)off[bounces] * 4));  // shadow masks and child flags
 	RT_CHECK(ctx->d_child_slot.reserve((size_t)off[bounces] * 8));  // [node][branch] -> child index (k_combine's pull form)
+	// The shared descent of every (group of 64 nodes, light) of a level (k_shadow_prefix): tuning.shadow_prefix = the most
+	// siblings a record may carry (they start on the rays' LDS stacks), 0 = every ray descends from the root by itself.
+	const int max_push = std::min(ctx->tuning.shadow_prefix, PREFIX_MAX);
+	// The walks are one kernel whose length is that of its longest walk (~1 us per node: a chain of dependent fetches),
+	// whatever the size of the frame: it pays once the level's shadow rays fill the machine several times over.  Below
+	// that (an 1/4 or 1/8 share of a 1080p frame) the shadow launches are as long as their slowest wave and the walks cost
+	// more than they save: 0.430 -> 0.454 ms for a quarter of the 1080p frame, 0.592 -> 0.574 ms for a half.
+	const bool use_prefix = shadows && !(sv.num_spheres > 0 && sv.num_tris == 0) && sv.use_bvh && sv.num_tris > 0 && max_push > 0 &&
+	                        (int64_t)n0 * sv.num_lights >= (ctx->tuning.shadow_prefix_min_rays < 0 ? (int64_t)6 * ctx->resident_threads : (int64_t)ctx->tuning.shadow_prefix_min_rays);
+	// Level 0 only: its groups are the frame's 8x8 tiles.  Deeper levels are compactions of their parents, 64 consecutive
+	// nodes of them lie too far apart for a shared descent (measured: the level-1 launch 235 -> 232 us for 35 us of walks).
+	const int64_t groups0 = ((int64_t)n0 + 63) / 64;
+	if (use_prefix) {
+		RT_CHECK(ctx->d_group_boxes.reserve((size_t)groups0 * sizeof(GroupBox)));
+		RT_CHECK(ctx->d_prefix.reserve((size_t)groups0 * sv.num_lights * PREFIX_INTS * sizeof(int)));
+	}
+	auto level_prefix = [&](int L) -> int* { return (use_prefix && L == 0) ? ctx->d_prefix.as<int>() : nullptr; };
+	auto prefix_launch = [&](int L, int n) -> int {
+		if (!use_prefix || L != 0) return RT_HIP_OK;
+		// (the groups' boxes: k_init_spawn)
+		hipEvent_t t0, t1;  // (profile mode: its time is booked with the shadow launches it serves)
+		RT_CHECK(rt_next_trace_events(ctx, 3, &t0, &t1));
+		hipExtLaunchKernelGGL(k_shadow_prefix, dim3(nblocks(groups0 * sv.num_lights, BLOCK)), dim3(BLOCK), 0, st, t0, t1, 0u, sv,
+		                      (const GroupBox*)ctx->d_group_boxes.as<GroupBox>(), n, (const int*)nullptr, sv.num_lights, ctx->cfg.shadow_t_max,
+		                      max_push, ctx->tuning.shadow_prefix_steps, level_prefix(0));
+		RT_HIP_CHECK(hipGetLastError());
+		return RT_HIP_OK;
+	};
 	auto shadow_launch = [&](const NodeGeo* geo, int n, const int* n_ptr, int lo, int hi, unsigned int* occl,
-	                         const int* q_count) -> int {
+	                         const int* q_count, const int* prefix) -> int {
 		FusedQueue fq{};
 		unsigned long long* cen = rt_census_ptr(ctx, 1);
 		if (q_count) {
@@ -1440,16 +1695,17 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		}
 		if (hi <= lo && !q_count) return RT_HIP_OK;
 		const size_t lds = rt_trace_lds(sv, TRACE_BLOCK);
-		const int blocks = rt_trace_blocks(ctx, std::max<int64_t>((int64_t)n * (hi - lo), n), TRACE_BLOCK);
+		const int64_t npad = prefix ? ((int64_t)n + 63) / 64 * 64 : n;
+		const int blocks = rt_trace_blocks(ctx, std::max<int64_t>(npad * (hi - lo), n), TRACE_BLOCK);
 		// timed (profile mode) through the dispatch itself: no event markers between the frame's kernels
 		hipEvent_t t0, t1;
 		RT_CHECK(rt_next_trace_events(ctx, 1, &t0, &t1));
 		if (cen)
 			hipExtLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(TRACE_BLOCK), (uint32_t)lds, st, t0, t1, 0u, sv, geo, n, n_ptr, lo, hi,
-			                      ctx->cfg.shadow_t_max, occl, cen, fq);
+			                      ctx->cfg.shadow_t_max, occl, cen, fq, prefix);
 		else
 			hipExtLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(TRACE_BLOCK), (uint32_t)lds, st, t0, t1, 0u, sv, geo, n, n_ptr, lo, hi,
-			                      ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr, fq);
+			                      ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr, fq, prefix);
 		RT_HIP_CHECK(hipGetLastError());
 		return RT_HIP_OK;
 	};
@@ -1472,7 +1728,8 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		if (L == 0) {
 			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
 			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, fs, w, h, n0,
-			                   tile, rank, nranks, recurse ? 1 : 0, geo, (float*)nullptr, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0));
+			                   tile, rank, nranks, recurse ? 1 : 0, geo, (float*)nullptr, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0),
+			                   use_prefix ? ctx->d_group_boxes.as<GroupBox>() : (GroupBox*)nullptr);
 		} else if (recurse) {
 			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created.  The last
 			// level needs nothing here: no rays to spawn, the light term is k_combine's, NodeShade stays unwritten.
@@ -1483,8 +1740,10 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		}
 		RT_HIP_CHECK(hipGetLastError());
 		const int nl = sv.num_lights, nl_a = (recurse && fuse) ? nl / 2 : nl;
+		RT_CHECK(prefix_launch(L, n));
+		const int* prefix = level_prefix(L);
 		if (!recurse) {
-			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr));
+			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr, prefix));
 			break;
 		}
 		NodeGeo* child_geo = ctx->d_nodes_a.as<NodeGeo>() + off[L + 1];
@@ -1493,10 +1752,10 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		const int child_cap = (int)cap[L + 1];
 		const Hit* raw = nullptr;                      // fused: children are made straight from the raw hits
 		if (fuse) {
-			RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl_a, occl, lc + 1));
+			RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl_a, occl, lc + 1, prefix));
 			raw = ctx->d_hits.as<Hit>();
 		} else {
-			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr));
+			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr, prefix));
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 1));
 		}
 		// texcoords of the children: from the queue's raw hits (trace_queue leaves them in d_hits for triangles)
@@ -1508,7 +1767,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo,
 		                   L == 0 ? (const float*)nullptr : (const float*)(inc_base + 3 * (size_t)off[L]), n, n_ptr, gate, q_org, q_dir, q_parent, lc + 2);
 		RT_HIP_CHECK(hipGetLastError());
-		if (fuse) RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2));
+		if (fuse) RT_CHECK(shadow_launch(geo, n, n_ptr, nl_a, nl, occl, lc + 2, prefix));
 		else RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
 		                   lc + 2, 1, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
@@ -1731,11 +1990,11 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			unsigned long long* cen = rt_census_ptr(ctx, 1);
 			if (cen)
 				hipLaunchKernelGGL(k_shadow<true>, dim3(rt_trace_blocks(ctx, total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
-				                   (const int*)nullptr, 0, sv.num_lights, ctx->cfg.shadow_t_max, occl, cen, FusedQueue{});
+				                   (const int*)nullptr, 0, sv.num_lights, ctx->cfg.shadow_t_max, occl, cen, FusedQueue{}, (const int*)nullptr);
 			else
 				hipLaunchKernelGGL(k_shadow<false>, dim3(rt_trace_blocks(ctx, total, TRACE_BLOCK)), dim3(TRACE_BLOCK), lds, st, sv, geo, n,
 				                   (const int*)nullptr, 0, sv.num_lights, ctx->cfg.shadow_t_max, occl, (unsigned long long*)nullptr,
-				                   FusedQueue{});
+				                   FusedQueue{}, (const int*)nullptr);
 			RT_HIP_CHECK(hipGetLastError());
 			RT_CHECK(rt_end_trace_timing(ctx, 1));
 			int64_t issued = (int64_t)(L == 0 ? active0 : n) * sv.num_lights;  // only active nodes trace

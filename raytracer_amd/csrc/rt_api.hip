@@ -96,6 +96,9 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->gather_fine_cells = env_int("RT_HIP_GATHER_FINE_CELLS", 8);
 	t->gather_medium = 4096;
 	if (const char* e = getenv("RT_HIP_GATHER_MEDIUM")) t->gather_medium = (uint32_t)strtoul(e, nullptr, 10);
+	t->shadow_prefix = env_int("RT_HIP_SHADOW_PREFIX", 12);
+	t->shadow_prefix_steps = env_int("RT_HIP_SHADOW_PREFIX_STEPS", 24);
+	t->shadow_prefix_min_rays = env_int("RT_HIP_SHADOW_PREFIX_MIN_RAYS", -1);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
@@ -118,6 +121,8 @@ void rt_clamp_tuning(rt_hip_ctx* ctx)
 	t.gather_fine_cells = std::min(32, std::max(2, t.gather_fine_cells));
 	t.extra_lds_bytes = std::min(64 * 1024, std::max(0, t.extra_lds_bytes));
 	t.max_bvh_depth = std::min(95, std::max(1, t.max_bvh_depth));
+	t.shadow_prefix = std::min(30, std::max(0, t.shadow_prefix));
+	t.shadow_prefix_steps = std::min(1024, std::max(1, t.shadow_prefix_steps));
 	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;
 }
 
@@ -207,7 +212,8 @@ int rt_end_trace_timing(rt_hip_ctx* ctx, int cls, hipStream_t st)
 int rt_next_trace_events(rt_hip_ctx* ctx, int cls, hipEvent_t* a, hipEvent_t* b)
 {
 	*a = *b = nullptr;
-	if (cls) ctx->stats.any_launches += 1; else ctx->stats.closest_launches += 1;
+	// cls 3: time that belongs to the any-hit launches without being one (the shadow rays' shared descent, k_shadow_prefix)
+	if (cls == 3) {} else if (cls) ctx->stats.any_launches += 1; else ctx->stats.closest_launches += 1;
 	if (!ctx->cfg.profile) return RT_HIP_OK;
 	if (ctx->trace_events_used == ctx->trace_events.size()) {
 		hipEvent_t x, y;
@@ -388,7 +394,7 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	                  &ctx->d_rank, &ctx->d_counts, &ctx->d_nodes_a, &ctx->d_nodes_b, &ctx->d_rays_q, &ctx->d_ray_parent,
 	                  &ctx->d_accum, &ctx->d_qcount, &ctx->d_gate, &ctx->d_photons, &ctx->d_photon_cell, &ctx->d_photon_sorted,
 	                  &ctx->d_cell_start, &ctx->d_photon_tmp, &ctx->d_census, &ctx->d_spill, &ctx->d_ploc, &ctx->d_tile_list, &ctx->d_all_tiles,
-	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_child_slot, &ctx->d_fcount, &ctx->d_leaf_order, &ctx->d_photon_emit, &ctx->d_level_nodes,
+	                  &ctx->d_tex, &ctx->d_texels, &ctx->d_node_uv, &ctx->d_heavy, &ctx->d_node_inc, &ctx->d_child_slot, &ctx->d_group_boxes, &ctx->d_prefix, &ctx->d_fcount, &ctx->d_leaf_order, &ctx->d_photon_emit, &ctx->d_level_nodes,
 	                  &ctx->d_mg_send, &ctx->d_mg_recv, &ctx->d_mg_counts, &ctx->d_mg_photons,
 	                  &ctx->d_photons_f, &ctx->d_photon_sorted_f, &ctx->d_cell_start_f};
 	for (DevBuf* b : bufs) b->release();

@@ -179,7 +179,7 @@ struct rt_hip_ctx {
 
 	// per-call scratch in HBM
 	DevBuf d_org, d_dir, d_hits, d_occ, d_in_a, d_in_b, d_records, d_offsets, d_keys, d_rank, d_counts;
-	DevBuf d_nodes_a, d_nodes_b, d_rays_q, d_ray_parent, d_accum, d_qcount, d_gate, d_node_uv, d_node_inc, d_fcount, d_child_slot;
+	DevBuf d_nodes_a, d_nodes_b, d_rays_q, d_ray_parent, d_accum, d_qcount, d_gate, d_node_uv, d_node_inc, d_fcount, d_child_slot, d_group_boxes, d_prefix;
 	const int* fcount_clean = nullptr;  // sync-free frame driver: d_fcount[0, fcount_clean_n) is known to be zero
 	int fcount_clean_n = 0;
 	// pinned host staging

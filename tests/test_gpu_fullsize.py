@@ -105,6 +105,34 @@ def test_c3_frame_drivers_agree_and_repeat(rt, torch, c3):
     assert int(c3["frame"].view(-1, 4)[:, :3].max()) > 60
 
 
+def test_c3_shared_descent_changes_no_pixel(rt, torch, c3):
+    """tuning.shadow_prefix: the descent the 64 shadow rays of an 8x8 tile share is made once per (tile, light) and the
+    rays start below it (k_shadow_prefix).  It may only ever add visits, so the frame must be the one every ray
+    renders from the root (shadow_prefix = 0) bit for bit, whatever the limits of the shared walk -- also with the
+    reference's literal shadows (no t_max on the shadow rays)."""
+    g = c3["g"]
+    default = g.tuning()
+    assert default["shadow_prefix"] > 0 and default["shadow_prefix_steps"] > 0
+    try:
+        for push, steps in ((0, 24), (1, 1), (3, 200), (12, 5), (30, 1024)):
+            g.set_tuning(shadow_prefix=push, shadow_prefix_steps=steps)
+            out = torch.zeros_like(c3["frame"])
+            g.render_frame_device(c3["d_p"], c3["d_n"], W, H, out)
+            assert torch.equal(out, c3["frame"]) and g.last_frame_rays() == c3["rays"], (push, steps)
+    finally:
+        g.set_tuning(shadow_prefix=default["shadow_prefix"], shadow_prefix_steps=default["shadow_prefix_steps"])
+    lit = rt.RtHip(c3["sc"], semantics="array", accel=rt.ACCEL_PLOC, bounces=2, do_shadows=1, shadow_t_max=0.0)
+    imgs = []
+    for push in (0, 12):
+        lit.set_tuning(shadow_prefix=push)
+        out = torch.zeros_like(c3["frame"])
+        lit.render_frame_device(c3["d_p"], c3["d_n"], W, H, out)
+        imgs.append(out)
+    lit.close()
+    assert torch.equal(imgs[0], imgs[1])
+    assert not torch.equal(imgs[0], c3["frame"])      # (literal shadows are darker: the two modes differ)
+
+
 @pytest.mark.parametrize("nranks", [2, 8])
 def test_c3_tile_split_reassembles_the_frame(rt, torch, c3, nranks):
     """Every virtual rank renders its 64x64 tiles of the 1080p frame straight into its packed chunk; unpacking the

@@ -326,6 +326,41 @@ def test_render_frame(rt, oracle_cls, scene_fn, accel, shadows, bounces, stmax, 
     g.close()
 
 
+@pytest.mark.parametrize("scene_fn,accel", [(scenes.cornell, 2), (lambda: scenes.atrium(2048), 3), (lambda: scenes.atrium(8192), 2)],
+                         ids=["cornell-lbvh", "atrium2k-ploc", "atrium8k-lbvh"])
+@pytest.mark.parametrize("stmax", [0.0, 1.0], ids=["literal", "corrected"])
+def test_render_frame_with_the_shared_descent(rt, oracle_cls, scene_fn, accel, stmax):
+    """k_shadow_prefix at oracle size: the shared descent is forced on for this small frame (shadow_prefix_min_rays = 0;
+    by default only frames that fill the machine use it), with a short, a usual and an unlimited walk, whole frame and
+    packed tile split.  The oracle traces every shadow ray by exhaustive search: images equal to max-abs 1, rays equal."""
+    torch = _torch()
+    sc = scene_fn()
+    orc = oracle_cls(sc)
+    w, h = 100, 75
+    nr, po, mid, nrm = _frame_inputs(orc, sc, w, h)
+    exp_rgba, _, exp_rays = orc.render_texels(po, nrm, mid, bounces=2, do_shadows=1, shadow_t_max=stmax)
+    g = rt.RtHip(sc, semantics="array", accel=accel, bounces=2, do_shadows=1, shadow_t_max=stmax)
+    base = np.asarray(g.render_frame(po, nr, w, h)).copy()       # default tuning: every ray from the root at this size
+    for push, steps in ((1, 2), (12, 24), (30, 1024)):
+        g.set_tuning(shadow_prefix=push, shadow_prefix_steps=steps, shadow_prefix_min_rays=0)
+        got = np.asarray(g.render_frame(po, nr, w, h))
+        assert np.array_equal(got, base), (push, steps)
+        assert g.last_frame_rays() == exp_rays
+    diff = np.abs(base.astype(np.int32) - exp_rgba.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    # the split frame: level 0 holds the rank's 8x8 blocks tile after tile
+    from raytracer_amd.tiles import max_owned_tiles
+    d_p, d_n = torch.from_numpy(po).cuda(), torch.from_numpy(nr).cuda()
+    chunk = max_owned_tiles(w, h, 16, 3) * 16 * 16 * 4
+    recv = torch.zeros(3 * chunk, dtype=torch.uint8, device="cuda")
+    for r in range(3):
+        g.render_tiles_packed_device([d_p], [d_n], w, h, 16, r, 3, [recv[r * chunk:(r + 1) * chunk]])
+    out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    g.unpack_chunks_device(recv, chunk, w, h, 16, 3, out)
+    assert np.array_equal(out.cpu().numpy().reshape(base.shape), base)
+    g.close()
+
+
 def test_render_tiles_partition(rt, oracle_cls):
     """Interleaved tile split: the union over ranks equals the single-GPU frame bit for bit."""
     torch = _torch()
