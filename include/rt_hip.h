@@ -416,6 +416,26 @@ int rt_hip_live_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const
                              int width, int height, int interlace, int phase, uint8_t* d_raypass_rgb8,
                              uint8_t* d_rgba_out, int* out_rays);
 
+/* The same with the reference's two sizes (Rasterizer::prepass_resolution = 0.75, ras_rasterizer.cpp:39,167-168): the rays
+ * start from a prepass_width x prepass_height G-buffer (select, ray generation and closest hit as above); each hit is drawn
+ * as drawRayData draws its point (ras_rasterizer.cpp:619-669, viewport = the prepass size): at the projection of Ray.origin
+ * through projectionFromCamera's matrix (:140-153, n = 1, f = 100, the frame's aspect ratio; mesh_vs.cpp:17), GL clip test,
+ * the texel that contains the window position -- so an origin that went through FP16 can land beside the texel it came
+ * from, and records that share a texel overwrite each other (GL: the last one drawn; here: one of them); the frame is
+ * composed at width x height from the full-size G-buffer (the stand-in for drawMeshes' rasterisation), the reflection
+ * term read as texture2D(raypassBuffer, gl_FragCoord.st / frame_size) reads it (mesh_fs.cpp:46): bilinear (GL_LINEAR,
+ * :600-601) with the default GL_REPEAT wrap.  With the two sizes equal the composite is rt_hip_live_frame_device's.
+ * fov as rt_hip_render_gbuffer_device takes it: tan(fov) scales the image plane (data/camera.cpp:19-44), and the matrix here is
+ * built from that same scale so that a point projects back onto the texel of a G-buffer made with it.  (The reference's matrix
+ * takes tan() of Camera::getFOV(), which already is a tangent -- ras_rasterizer.cpp:143, camera.cpp:41-44,60-63 -- so its raster
+ * camera is tan(tan(fov)); it is consistent with itself because its G-buffer is rasterised through that same matrix.  A caller
+ * whose G-buffer comes from that rasterizer passes atan(tan(tan(fov))).)
+ * d_raypass_rgb8: prepass_width * prepass_height * 3 bytes, persistent across calls, filled with 255 once by the caller.
+ * Parity unpinned (GL is not available; filtering precision and the order of overlapping points are GL's own). */
+int rt_hip_live_frame_scaled_device(rt_hip_ctx* ctx, const float* d_prepass_pos_rgb, const float* d_prepass_nrm_rgba, int prepass_width,
+                                    int prepass_height, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width, int height,
+                                    float fov, int interlace, int phase, uint8_t* d_raypass_rgb8, uint8_t* d_rgba_out, int* out_rays);
+
 /* ---- live shading of the hit records (the raypass) ------------------------------------------ */
 /* rasterizer/shaders/mesh_fs.cpp:26-49 evaluated at each hit record the way Rasterizer::drawRayData
  * (ras_rasterizer.cpp:619-669) draws it: one point per record with its group's material, the

@@ -308,6 +308,52 @@ class Oracle:
         return out
 
 
+# ---- the GL side of the live frame with a prepass smaller than the frame (numpy restatement, float32 like a shader) ----
+def raster_point_texel(pos, fov, frame_w, frame_h, pw, ph):
+    """Where drawRayData's GL_POINTS land (ras_rasterizer.cpp:619-669, viewport = prepass size): gl_Position = proj_mat *
+    vec4(Ray.origin, 1) (mesh_vs.cpp:17) with projectionFromCamera's matrix (ras_rasterizer.cpp:140-153: n = 1, f = 100,
+    r = frame aspect * scale, t = scale), GL's clip test, viewport transform, and the fragment of a size-1 point = the texel
+    containing the window position.  scale = tan(fov) as this build's G-buffer camera has it (the reference applies tan() to an
+    already-tan'd value, ras_rasterizer.cpp:143 / camera.cpp:41-44,60-63; it is self-consistent, and so is this).
+    Returns the texel index per point, -1 = clipped.  Parity unpinned (no GL here)."""
+    f32 = np.float32
+    P = np.asarray(pos, np.float32).reshape(-1, 3)
+    n_, f_ = f32(1.0), f32(100.0)
+    scale = f32(np.tan(np.float64(f32(fov))) * np.float64(n_))
+    r = f32(frame_w) / f32(frame_h) * scale
+    t = scale
+    m00, m11 = n_ / r, n_ / t
+    m22, m32 = -(f_ + n_) / (f_ - n_), f32(-2) * f_ * n_ / (f_ - n_)
+    cx, cy, cz, cw = m00 * P[:, 0], m11 * P[:, 1], m22 * P[:, 2] + m32, -P[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inside = (cx >= -cw) & (cx <= cw) & (cy >= -cw) & (cy <= cw) & (cz >= -cw) & (cz <= cw)
+        xw = (cx / cw) * (f32(0.5) * f32(pw)) + f32(0.5) * f32(pw)
+        yw = (cy / cw) * (f32(0.5) * f32(ph)) + f32(0.5) * f32(ph)
+    xw, yw = np.where(inside, xw, f32(-1)), np.where(inside, yw, f32(-1))
+    ix, iy = np.floor(xw).astype(np.int64), np.floor(yw).astype(np.int64)
+    ok = inside & (ix >= 0) & (ix < pw) & (iy >= 0) & (iy < ph)
+    return np.where(ok, iy * pw + ix, -1).astype(np.int64)
+
+
+def raypass_linear(raypass_u8, pw, ph, w, h):
+    """texture2D(raypassBuffer, gl_FragCoord.st / frame_size) (mesh_fs.cpp:46) for every pixel of a w x h frame: the pw x ph
+    RGB8 raypass target (UNORM8 -> c / 255) with GL_LINEAR filters (ras_rasterizer.cpp:600-601) and the default GL_REPEAT
+    wrap.  Returns (w * h, 3) float32.  Parity unpinned (filter precision is the GL implementation's)."""
+    f32 = np.float32
+    T = np.asarray(raypass_u8, np.uint8).reshape(ph, pw, 3).astype(np.float32) / f32(255.0)
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    u, v = (xs + f32(0.5)) / f32(w), (ys + f32(0.5)) / f32(h)
+    x, y = u * f32(pw) - f32(0.5), v * f32(ph) - f32(0.5)
+    fx, fy = np.floor(x), np.floor(y)
+    a, b = (x - fx)[..., None], (y - fy)[..., None]
+    x0, y0 = np.mod(fx.astype(np.int64), pw), np.mod(fy.astype(np.int64), ph)
+    x1, y1 = (x0 + 1) % pw, (y0 + 1) % ph
+    one = f32(1.0)
+    lo = T[y0, x0] * (one - a) + T[y0, x1] * a
+    hi = T[y1, x0] * (one - a) + T[y1, x1] * a
+    return (lo * (one - b) + hi * b).reshape(-1, 3).astype(np.float32)
+
+
 class Ref:
     """The compiled reference behind oracle/ref_harness.cpp (process-global state)."""
 

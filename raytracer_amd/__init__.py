@@ -76,7 +76,7 @@ ABI_SYMBOLS = [
     "rt_hip_render_frame_device", "rt_hip_render_tiles_device", "rt_hip_last_frame_rays", "rt_hip_photon_emit_device",
     "rt_hip_photon_set_device", "rt_hip_photon_set", "rt_hip_radiance_estimate_device", "rt_hip_radiance_estimate",
     "rt_hip_shade_results", "rt_hip_shade_results_device", "rt_hip_pack_tiles_device", "rt_hip_unpack_tiles_device",
-    "rt_hip_render_tiles_batch_device", "rt_hip_live_frame_device", "rt_hip_render_tiles_packed_device",
+    "rt_hip_render_tiles_batch_device", "rt_hip_live_frame_device", "rt_hip_live_frame_scaled_device", "rt_hip_render_tiles_packed_device",
     "rt_hip_unpack_chunks_device", "rt_hip_set_texture", "rt_hip_set_frame_texcoords_device",
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
@@ -166,6 +166,7 @@ def load_library() -> C.CDLL:
     L.rt_hip_render_tiles_packed_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_unpack_chunks_device.argtypes = [P, P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_live_frame_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, C.POINTER(C.c_int)]
+    L.rt_hip_live_frame_scaled_device.argtypes = [P, P, P, C.c_int, C.c_int, P, P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, P, P, C.POINTER(C.c_int)]
     L.rt_hip_pack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
     L.rt_hip_unpack_tiles_device.argtypes = [P, P, C.c_int, C.c_int, C.c_int, P, C.c_int, P]
     L.rt_hip_shade_results.argtypes = [P, P, P, C.c_int, C.c_int, c_float_p, P]
@@ -502,6 +503,13 @@ class RtHip:
         rays = C.c_int(0)
         self._ck(self.lib.rt_hip_live_frame_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, interlace, phase,
                                                    _dptr(d_raypass_rgb8), _dptr(d_rgba), C.byref(rays)))
+        return rays.value
+
+    def live_frame_scaled_device(self, d_pre_pos, d_pre_nrm, pw, ph, d_pos_rgb, d_nrm_rgba, w, h, fov, interlace, phase, d_raypass_rgb8, d_rgba):
+        """rt_hip_live_frame_scaled_device: prepass (pw x ph) and frame (w x h) of different sizes (ras_rasterizer.cpp:39,167-168)."""
+        rays = C.c_int(0)
+        self._ck(self.lib.rt_hip_live_frame_scaled_device(self.h, _dptr(d_pre_pos), _dptr(d_pre_nrm), pw, ph, _dptr(d_pos_rgb), _dptr(d_nrm_rgba),
+                                                          w, h, float(fov), interlace, phase, _dptr(d_raypass_rgb8), _dptr(d_rgba), C.byref(rays)))
         return rays.value
 
     def render_tiles_packed_device(self, d_pos_list, d_nrm_list, w, h, tile, rank, nranks, d_packed_list):

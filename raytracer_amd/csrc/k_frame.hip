@@ -1225,6 +1225,91 @@ __global__ __launch_bounds__(BLOCK) void k_live_composite(SceneView sv, const fl
 	px[0] = unorm8(c.x); px[1] = unorm8(c.y); px[2] = unorm8(c.z); px[3] = 255;
 }
 
+// ---- the live frame with a prepass smaller than the frame (ras_rasterizer.cpp:39,167-168: 0.75) -------------
+// proj_mat of projectionFromCamera (ras_rasterizer.cpp:140-153; n = 1, f = 100, the FRAME's aspect ratio) applied to a
+// point as mesh_vs.cpp:17 applies it (transform_draw = 0: no model matrix), then GL's clip test and viewport
+// transform onto a pw x ph target and the rasterisation of a size-1 point: the fragment that contains the window
+// position.  Returns the texel, or -1 when the point is clipped.
+struct LiveProj {
+	float m00, m11, m22, m32;
+	int pw, ph;
+};
+__device__ __forceinline__ int live_point_texel(const LiveProj& pr, f3 P)
+{
+	const float cx = pr.m00 * P.x, cy = pr.m11 * P.y, cz = pr.m22 * P.z + pr.m32, cw = -P.z;
+	if (!(cx >= -cw && cx <= cw && cy >= -cw && cy <= cw && cz >= -cw && cz <= cw)) return -1;  // (also w <= 0 and NaN)
+	const float xw = (cx / cw) * (0.5f * (float)pr.pw) + 0.5f * (float)pr.pw;
+	const float yw = (cy / cw) * (0.5f * (float)pr.ph) + 0.5f * (float)pr.ph;
+	const int ix = (int)floorf(xw), iy = (int)floorf(yw);
+	if (ix < 0 || ix >= pr.pw || iy < 0 || iy >= pr.ph) return -1;
+	return iy * pr.pw + ix;
+}
+
+// drawRayData's points (ras_rasterizer.cpp:619-669): every hit record is drawn at the projection of Ray.origin
+// (mesh_vs.cpp:17, location 0) into the prepass-sized raypass target and shaded at the hit.  Several records can land on
+// one texel (the origin went through FP16); GL keeps the last one drawn, here: an unspecified one of them.
+__global__ __launch_bounds__(BLOCK) void k_live_raypass_proj(SceneView sv, const Hit* __restrict__ hits, const float* __restrict__ org,
+                                                             int n, LiveProj pr, uint8_t* __restrict__ raypass)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= n) return;
+	HitInfo hi;
+	float tc[2] = {0.0f, 0.0f};
+	resolve_tri(sv, hits[i], hi, sv.tex ? tc : nullptr);
+	if (hi.material < 0) return;
+	const int texel = live_point_texel(pr, ld3(org + 3 * (size_t)i));
+	if (texel < 0) return;
+	const MaterialRec m = sv.materials[hi.material];
+	f3 c = mesh_fs_color(sv, m, live_albedo(sv, hi.material, m, tc[0], tc[1]), ld3(hi.pos), ld3(hi.nrm), mk3(0, 0, 0));
+	uint8_t* px = raypass + 3 * (size_t)texel;
+	px[0] = unorm8(c.x); px[1] = unorm8(c.y); px[2] = unorm8(c.z);
+}
+
+// texture2D(raypassBuffer, gl_FragCoord.st / frame_size) (mesh_fs.cpp:46) on the pw x ph RGB8 target with GL_LINEAR
+// filters (ras_rasterizer.cpp:600-601) and the default GL_REPEAT wrap: bilinear between the four texels around
+// (u pw - 0.5, v ph - 0.5), indices taken modulo the size.
+__device__ __forceinline__ f3 raypass_linear(const uint8_t* __restrict__ raypass, int pw, int ph, float u, float v)
+{
+	const float x = u * (float)pw - 0.5f, y = v * (float)ph - 0.5f;
+	const float fx = floorf(x), fy = floorf(y);
+	const float a = x - fx, b = y - fy;
+	int x0 = (int)fx % pw, y0 = (int)fy % ph;
+	if (x0 < 0) x0 += pw;
+	if (y0 < 0) y0 += ph;
+	const int x1 = (x0 + 1) % pw, y1 = (y0 + 1) % ph;
+	auto tx = [&](int xx, int yy) {
+		const uint8_t* p = raypass + 3 * ((size_t)yy * pw + xx);
+		return mk3(p[0] / 255.0f, p[1] / 255.0f, p[2] / 255.0f);
+	};
+	const f3 t00 = tx(x0, y0), t10 = tx(x1, y0), t01 = tx(x0, y1), t11 = tx(x1, y1);
+	const f3 lo = t00 * (1.0f - a) + t10 * a, hi = t01 * (1.0f - a) + t11 * a;
+	return lo * (1.0f - b) + hi * b;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_live_composite_scaled(SceneView sv, const float* __restrict__ pos_rgb,
+                                                                 const float* __restrict__ nrm_rgba, int w, int h,
+                                                                 const uint8_t* __restrict__ raypass, int pw, int ph,
+                                                                 uint8_t* __restrict__ rgba, const float* __restrict__ uv)
+{
+	int i = blockIdx.x * BLOCK + threadIdx.x;
+	if (i >= w * h) return;
+	float a = nrm_rgba[4 * (size_t)i + 3];
+	int mat = (a > 0.0f) ? ((int)a - 1) : -1;
+	if (mat >= sv.num_materials) mat = -1;
+	uint8_t* px = rgba + 4 * (size_t)i;
+	if (mat < 0) { px[0] = px[1] = px[2] = unorm8(0.3f); px[3] = 255; return; }
+	f3 N;
+	N.x = (float)((double)nrm_rgba[4 * (size_t)i + 0] * 2.0 - 1.0);
+	N.y = (float)((double)nrm_rgba[4 * (size_t)i + 1] * 2.0 - 1.0);
+	N.z = (float)((double)nrm_rgba[4 * (size_t)i + 2] * 2.0 - 1.0);
+	const int x = i % w, y = i / w;
+	const f3 refl = raypass_linear(raypass, pw, ph, ((float)x + 0.5f) / (float)w, ((float)y + 0.5f) / (float)h);
+	const MaterialRec m = sv.materials[mat];
+	const float tu = uv ? uv[2 * (size_t)i] : 0.0f, tv = uv ? uv[2 * (size_t)i + 1] : 0.0f;
+	f3 c = mesh_fs_color(sv, m, live_albedo(sv, mat, m, tu, tv), ld3(pos_rgb + 3 * (size_t)i), N, refl);
+	px[0] = unorm8(c.x); px[1] = unorm8(c.y); px[2] = unorm8(c.z); px[3] = 255;
+}
+
 // ---- live shading of hit records ---------------------------------------------------------------------
 // mesh_fs.cpp:26-49 at one hit record, as drawRayData draws it into the raypass target: the
 // record's group gives the material; reflection term = 0.  One lane per record.
@@ -1370,6 +1455,47 @@ int rt_live_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rg
 	}
 	hipLaunchKernelGGL(k_live_composite, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, d_pos_rgb, d_nrm_rgba, n,
 	                   d_raypass, d_rgba, ctx->frame_uv_count > 0 ? ctx->frame_uv[0] : (const float*)nullptr);
+	RT_HIP_CHECK(hipGetLastError());
+	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	RT_CHECK(rt_collect_timing(ctx));
+	*out_rays = count;
+	return RT_HIP_OK;
+}
+
+// The same with the reference's two sizes (ras_rasterizer.cpp:39,167-173): rays from a pw x ph prepass G-buffer, their
+// hits splatted into the pw x ph raypass image at the projection of the ray origin, the w x h frame composed from the
+// full-size G-buffer with a bilinear fetch of the raypass image.
+int rt_live_frame_scaled(rt_hip_ctx* ctx, const float* d_pre_pos, const float* d_pre_nrm, int pw, int ph, const float* d_pos_rgb,
+                         const float* d_nrm_rgba, int w, int h, float fov, int interlace, int phase, uint8_t* d_raypass,
+                         uint8_t* d_rgba, int* out_rays)
+{
+	const int n = pw * ph;
+	*out_rays = 0;
+	RT_CHECK(ctx->d_in_a.reserve((size_t)n * 12));
+	RT_CHECK(ctx->d_in_b.reserve((size_t)n * 12));
+	int count = 0;
+	RT_CHECK(rt_gbuffer_select(ctx, d_pre_nrm, d_pre_pos, n, interlace, phase, ctx->d_in_a.as<float>(), ctx->d_in_b.as<float>(),
+	                           nullptr, &count));
+	SceneView sv = rt_scene_view(ctx);
+	if (count > 0) {
+		// projectionFromCamera (ras_rasterizer.cpp:140-153)
+		const float nn = 1.0f, ff = 100.0f;
+		const float scale = (float)(tan((double)fov) * nn);
+		const float r = ((float)w) / h * scale, t = scale;
+		LiveProj pr;
+		pr.m00 = nn / r; pr.m11 = nn / t; pr.m22 = -(ff + nn) / (ff - nn); pr.m32 = -2 * ff * nn / (ff - nn);
+		pr.pw = pw; pr.ph = ph;
+		RT_CHECK(ctx->d_org.reserve((size_t)count * 12));
+		RT_CHECK(ctx->d_dir.reserve((size_t)count * 12));
+		RT_CHECK(ctx->d_hits.reserve((size_t)count * sizeof(Hit)));
+		RT_CHECK(rt_launch_reflect_raygen(ctx, ctx->d_in_a.as<float>(), ctx->d_in_b.as<float>(), count, ctx->d_org.as<float>(),
+		                                  ctx->d_dir.as<float>()));
+		RT_CHECK(rt_launch_closest(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), count, ctx->d_hits.as<Hit>()));
+		hipLaunchKernelGGL(k_live_raypass_proj, dim3(nblocks(count, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, ctx->d_hits.as<Hit>(),
+		                   (const float*)ctx->d_org.as<float>(), count, pr, d_raypass);
+	}
+	hipLaunchKernelGGL(k_live_composite_scaled, dim3(nblocks((int64_t)w * h, BLOCK)), dim3(BLOCK), 0, ctx->stream, sv, d_pos_rgb, d_nrm_rgba,
+	                   w, h, (const uint8_t*)d_raypass, pw, ph, d_rgba, ctx->frame_uv_count > 0 ? ctx->frame_uv[0] : (const float*)nullptr);
 	RT_HIP_CHECK(hipGetLastError());
 	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	RT_CHECK(rt_collect_timing(ctx));

@@ -1165,6 +1165,28 @@ int rt_hip_live_frame_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const
 	return RT_HIP_OK;
 }
 
+int rt_hip_live_frame_scaled_device(rt_hip_ctx* ctx, const float* d_prepass_pos_rgb, const float* d_prepass_nrm_rgba, int prepass_width,
+                                    int prepass_height, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width, int height,
+                                    float fov, int interlace, int phase, uint8_t* d_raypass_rgb8, uint8_t* d_rgba_out, int* out_rays)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || prepass_width <= 0 || prepass_height <= 0 || !d_prepass_pos_rgb || !d_prepass_nrm_rgba ||
+	    !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_raypass_rgb8 || !d_rgba_out || (interlace > 1 && (phase < 0 || phase >= interlace))) {
+		rt_set_error("bad arguments");
+		return RT_HIP_ERR_ARG;
+	}
+	if (ctx->cfg.geometry != RT_HIP_TRIANGLES) { rt_set_error("the live frame needs triangle geometry"); return RT_HIP_ERR_STATE; }
+	if ((int64_t)width * height > (int64_t)1 << 28 || (int64_t)prepass_width * prepass_height > (int64_t)1 << 28) {
+		rt_set_error("frame larger than 2^28 texels");
+		return RT_HIP_ERR_LIMIT;
+	}
+	int rays = 0;
+	RT_CHECK(rt_live_frame_scaled(ctx, d_prepass_pos_rgb, d_prepass_nrm_rgba, prepass_width, prepass_height, d_gbuf_pos_rgb, d_gbuf_nrm_rgba,
+	                              width, height, fov, interlace, phase, d_raypass_rgb8, d_rgba_out, &rays));
+	if (out_rays) *out_rays = rays;
+	return RT_HIP_OK;
+}
+
 // ---- packed tile exchange --------------------------------------------------------------------------
 static int check_tiles_args(const void* frame, int w, int h, int tile, const int* d_tile_list, int ntiles, const void* packed)
 {

@@ -259,6 +259,9 @@ int rt_launch_shade_results(rt_hip_ctx* ctx, const rt_ray* d_rec, int n, const r
                             float* d_rgb, uint8_t* d_rgb8);
 int rt_live_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int interlace, int phase,
                   uint8_t* d_raypass, uint8_t* d_rgba, int* out_rays);
+int rt_live_frame_scaled(rt_hip_ctx* ctx, const float* d_pre_pos, const float* d_pre_nrm, int pw, int ph, const float* d_pos_rgb,
+                         const float* d_nrm_rgba, int w, int h, float fov, int interlace, int phase, uint8_t* d_raypass,
+                         uint8_t* d_rgba, int* out_rays);
 int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, int h, int tile, const int* d_tile_list,
                          int ntiles, uint8_t* d_packed);
 int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb, float* d_uv = nullptr);

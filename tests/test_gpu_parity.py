@@ -616,6 +616,82 @@ def test_live_frame(rt, oracle_cls, scene_fn):
     g.close()
 
 
+@pytest.mark.parametrize("scene_fn", [scenes.cornell, lambda: scenes.atrium(2048)], ids=["cornell", "atrium2k"])
+def test_live_frame_with_a_smaller_prepass(rt, oracle_cls, scene_fn):
+    """rt_hip_live_frame_scaled_device: Rasterizer::prepass_resolution = 0.75 (ras_rasterizer.cpp:39,167-168).  Rays from the
+    72 x 48 prepass G-buffer, hits splatted at the projection of Ray.origin (mesh_vs.cpp:17) into the 72 x 48 raypass
+    image, the 96 x 64 frame composed with a bilinear fetch of it (mesh_fs.cpp:46).  Oracle: its pieces + the numpy
+    restatement of the two GL steps (oracle/pyoracle.py) -- parity unpinned, GL cannot run here.  Texels that receive more
+    than one point are GL's draw order (last wins): the GPU may keep any of them, they are compared as a set."""
+    torch = _torch()
+    from oracle.pyoracle import RAY_DTYPE, raster_point_texel, raypass_linear
+    sc = scene_fn()
+    orc = oracle_cls(sc)
+    w, h, pw, ph = 96, 64, 72, 48
+    nr, po = orc.software_gbuffer(w, h)
+    pnr, ppo = orc.software_gbuffer(pw, ph)
+    g = rt.RtHip(sc, accel=2)
+    d_p, d_n = torch.from_numpy(po).cuda(), torch.from_numpy(nr).cuda()
+    d_pp, d_pn = torch.from_numpy(ppo).cuda(), torch.from_numpy(pnr).cuda()
+    d_rp = torch.full((pw * ph, 3), 255, dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+    rp = np.full((pw * ph, 3), 255, np.uint8)
+    tm = _tri_material(sc)
+    mid = nr[:, 3].astype(np.int32) - 1
+    cov = mid >= 0
+    moved_total = 0
+    for interlace, phase in [(16, 3), (16, 0), (1, 0)]:
+        sel_pos, sel_nrm, sel_idx = orc.gbuffer_select(pnr, ppo, interlace, phase)
+        pr = orc.process_rays(sel_pos, sel_nrm)
+        hit = pr["tidx"] != MISS
+        ray_mat = np.where(hit, tm[np.where(hit, pr["tidx"], 0)], -1)
+        texel = raster_point_texel(sel_pos, sc.fov, w, h, pw, ph)            # Ray.origin = the selected position
+        moved_total += int((texel[hit] != sel_idx[hit]).sum())
+        cand = {}                                                            # texel -> colours of the points landing there
+        start = 0
+        for m, end in zip(pr["offset_material"], pr["offset_end"]):
+            rays = np.nonzero(hit & (ray_mat == m))[0]
+            rgb = orc.shade_records(pr["records"][start:end], np.full(end - start, m, np.int32))
+            c8 = np.rint(np.clip(rgb, 0, 1) * np.float32(255)).astype(np.uint8)
+            for k, ray in enumerate(rays):
+                if texel[ray] >= 0:
+                    cand.setdefault(int(texel[ray]), []).append(c8[k])
+            start = end
+        rays_gpu = g.live_frame_scaled_device(d_pp, d_pn, pw, ph, d_p, d_n, w, h, sc.fov, interlace, phase, d_rp, d_out)
+        assert rays_gpu == sel_pos.shape[0] > 0
+        got_rp, got = d_rp.cpu().numpy(), d_out.cpu().numpy()
+        bad = 0
+        for t, cols in cand.items():
+            if min(np.abs(got_rp[t].astype(int) - c.astype(int)).max() for c in cols) > 1:
+                bad += 1
+            rp[t] = got_rp[t]                                                # (the GPU's pick among the candidates)
+        assert bad <= 1e-3 * max(len(cand), 1) + 1                           # exact-t shared-edge ties, as in test_live_frame
+        untouched = np.ones(pw * ph, bool)
+        untouched[list(cand.keys())] = False
+        assert np.array_equal(got_rp[untouched], rp[untouched])              # nothing else was written
+        # composite from the full-size G-buffer with the bilinear raypass fetch
+        rec = np.zeros(int(cov.sum()), RAY_DTYPE)
+        rec["position"] = po[cov]
+        rec["normal"] = (nr[cov, :3].astype(np.float64) * 2.0 - 1.0).astype(np.float32)
+        shaded = orc.shade_records(rec, mid[cov])                            # (1 - refl) * direct
+        refl = np.array([m.reflectivity for m in sc.materials], np.float32)[mid[cov]][:, None]
+        col = refl * raypass_linear(rp, pw, ph, w, h)[cov] + shaded
+        exp = np.rint(np.clip(col, 0, 1) * np.float32(255)).astype(np.uint8)
+        d_img = np.abs(got[cov, :3].astype(int) - exp.astype(int)).max(1)
+        assert (d_img > 1).mean() <= 1e-3, (d_img > 1).mean()
+        assert (np.abs(got[~cov, :3].astype(int) - 76.5) <= 0.5).all() and (got[:, 3] == 255).all()
+    assert (rp != 255).any(1).sum() > 0.2 * (pnr[:, 3] > 0).sum()
+    # equal sizes: the scaled entry composes what the plain entry composes
+    d_rp1 = torch.full((w * h, 3), 255, dtype=torch.uint8, device="cuda")
+    d_rp2 = torch.full((w * h, 3), 255, dtype=torch.uint8, device="cuda")
+    d_o1, d_o2 = torch.zeros_like(d_out), torch.zeros_like(d_out)
+    g.live_frame_device(d_p, d_n, w, h, 1, 0, d_rp1, d_o1)
+    g.live_frame_scaled_device(d_p, d_n, w, h, d_p, d_n, w, h, sc.fov, 1, 0, d_rp2, d_o2)
+    same = (d_rp1 == d_rp2).all(1).float().mean().item()
+    assert same > 0.97                                                       # (points whose FP16 origin projects into the neighbouring texel)
+    g.close()
+
+
 def test_packed_render_and_unpack_chunks(rt, oracle_cls):
     """The exchange path of an N-GPU step on one GPU: every virtual rank renders its tiles of 3 frames
     straight into packed chunks; the chunks must equal pack_tiles() of the full frames, and
