@@ -8,15 +8,16 @@ metric ("secondary Mrays/s + ms/frame @1080p, 1/2/4/8 MI355X") is quoted on: a ~
 procedural atrium (real Sponza cannot be fetched offline), GPU-built BVH, 1080p G-buffer resident in
 HBM, Gen-1 shading with shadow + reflection + refraction rays, 2 bounces.
 
-A step = `config.frames_per_step` frames, so that the timed region lasts about a second and the
+A step = `config.frames_per_step` frames (300 at N = 1), so that the timed region lasts about five seconds and the
 driver's own GPU-busy sampling can see it.  Two ways to use N GPUs:
-  --scaling weak (default)  every sub-step renders N frames (N fields of view); each frame is split over
-        the ranks by interleaved 64x64 tiles, so a rank traces one frame's worth of texels (its tiles of
-        all N frames in ONE wavefront); one all-to-all per sub-step sends rank r's tiles of frame f to
-        rank f, overlapped with the next sub-step's kernels.  Per-GPU work is fixed.
-  --scaling strong          every sub-step renders ONE frame split over the N ranks; the finished tiles
-        are all-gathered (RCCL) and every rank assembles the whole frame before the next one starts,
-        so ms_per_frame is the latency of a frame.  Total work is fixed.
+  --scaling strong (default) every sub-step renders ONE frame split over the N ranks by interleaved 64x64 tiles, through the
+        C ABI alone (--route cabi: rt_hip_comm_init with the id broadcast over torch.distributed, then
+        rt_hip_render_frame_multi_device: tiles shaded into the packed chunk, ncclAllGather, unpack -- the whole image
+        on every rank before the next frame starts), so ms_per_frame is the latency of a frame.  Total work is fixed:
+        north_star's "the frame is partitioned across the 8 GPUs".  --route torch: the same through frames.py.
+  --scaling weak            every sub-step renders N frames (N fields of view); each frame is split over the ranks, so a
+        rank traces one frame's worth of texels (its tiles of all N frames in ONE wavefront); one all-to-all per
+        sub-step sends rank r's tiles of frame f to rank f, overlapped with the next sub-step's kernels.
 config.ms_per_frame is always wall time / frames completed by the whole job (1 / throughput);
 config.frame_latency_ms is the time from a frame's first kernel to its assembled image.
 
@@ -25,7 +26,7 @@ ranks), inputs resident in HBM.  roofline = the kernel with the most GPU time am
 of the frame (the fused shadow / closest-hit traversal k_shadow; with --photons the photon gather),
 priced against the resource the counters show it is bound by -- the vector ALU -- with frac <= 1:
 algorithmic FLOP (34 per BVH node visit, 45 per triangle test, counted on the device by a census pass
-over the identical frame) / launch time against the 157.3 TFLOP/s FP32 vector peak; the HBM side
+over the identical frame with every ray traced from the root by itself) / launch time against the 157.3 TFLOP/s FP32 vector peak; the HBM side
 (counter bytes per launch, offline rocprofv3 passes of this same command under profiles/) is reported
 beside it.  cpu_baseline = the compiled reference's own RayTracer::processRays (oracle/_ref, kind
 "reference") or the oracle's restatement (kind "port") on a bounded sample of the same G-buffer,
