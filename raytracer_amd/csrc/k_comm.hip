@@ -158,15 +158,20 @@ int rt_hip_render_frame_multi_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rg
 	}
 	uint8_t* send = ctx->d_mg_send.as<uint8_t>();
 	int64_t rays = 0;
-	{	// every communicator size takes this one path (a single rank owns all the tiles)
+	{	// every communicator size takes this one path (a single rank owns all the tiles).  The all-gather and the unpack are
+		// queued behind the frame's kernels before the host waits for the frame's counters: one host wait per frame.
 		const float* pos[1] = {d_gbuf_pos_rgb};
 		const float* nrm[1] = {d_gbuf_nrm_rgba};
 		uint8_t* out[1] = {send};
-		RT_CHECK(rt_render_frames(ctx, pos, nrm, 1, width, height, tile, rank, nranks, out, 1));
+		ctx->after_frame_queued = [&]() -> int {
+			RT_NCCL_CHECK(g_rccl.AllGather(send, ctx->d_mg_recv.p, chunk, ncclUint8, (ncclComm_t)ctx->comm, st));
+			return rt_unpack_chunks(ctx, ctx->d_mg_recv.as<uint8_t>(), (int64_t)chunk, width, height, tile, nranks, d_rgba_out);
+		};
+		const int status = rt_render_frames(ctx, pos, nrm, 1, width, height, tile, rank, nranks, out, 1);
+		ctx->after_frame_queued = nullptr;
+		RT_CHECK(status);
 		rays = ctx->last_frame_rays;
 	}
-	RT_NCCL_CHECK(g_rccl.AllGather(send, ctx->d_mg_recv.p, chunk, ncclUint8, (ncclComm_t)ctx->comm, st));
-	RT_CHECK(rt_unpack_chunks(ctx, ctx->d_mg_recv.as<uint8_t>(), (int64_t)chunk, width, height, tile, nranks, d_rgba_out));
 	RT_HIP_CHECK(hipStreamSynchronize(st));
 	ctx->last_frame_rays = rays;
 	return RT_HIP_OK;

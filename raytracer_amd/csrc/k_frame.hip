@@ -1744,7 +1744,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	const int n0 = fs.per_frame * fs.nframes;
 	pf->n0 = n0; pf->bounces = bounces; pf->nframes = fs.nframes; pf->num_lights = sv.num_lights; pf->rays = 0;
 	pf->trace_mark = ctx->trace_events_used;
-	if (n0 == 0) { *declined = false; pf->complete = true; return RT_HIP_OK; }  // this rank owns no tile
+	if (n0 == 0) { *declined = false; pf->complete = true; pf->can_overflow = false; return RT_HIP_OK; }  // this rank owns no tile
 	std::vector<int64_t> cap(bounces), off(bounces + 1, 0);
 	for (int L = 0; L < bounces; ++L) {
 		cap[L] = L == 0 ? n0 : std::min<int64_t>(2 * cap[L - 1], FRAME_LEVEL_CAP);
@@ -1752,6 +1752,8 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	}
 	if (n0 > FRAME_LEVEL_CAP || off[bounces] > FRAME_TOTAL_CAP) return RT_HIP_OK;  // too big to size by bounds
 	*declined = false;
+	pf->can_overflow = false;  // a level whose bound is the cap rather than twice its parent's can come out larger than its arrays
+	for (int L = 1; L < bounces; ++L) pf->can_overflow = pf->can_overflow || cap[L] < 2 * cap[L - 1];
 	const int64_t maxcap = *std::max_element(cap.begin(), cap.end());
 	RT_CHECK(ctx->d_nodes_a.reserve((size_t)off[bounces] * sizeof(NodeGeo)));
 	RT_CHECK(ctx->d_nodes_b.reserve((size_t)off[bounces] * sizeof(NodeShade)));
@@ -1972,7 +1974,14 @@ static int render_frame_async(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int ti
 	PendingFrame* pf = &ctx->pending[0];
 	RT_CHECK(frame_async_enqueue(ctx, fs, w, h, tile, rank, nranks, pf, declined));
 	if (*declined) return RT_HIP_OK;
-	return frame_async_finish(ctx, pf, overflowed);
+	// The hook runs exactly once per rt_render_frames call (it may hold a collective, which every rank must enter the same
+	// number of times): here, ahead of the host's wait, when no level of this frame can overflow its bound; otherwise after
+	// the wait, or after the frame has been redone.
+	const bool early = ctx->after_frame_queued && !pf->can_overflow;
+	if (early) RT_CHECK(ctx->after_frame_queued());
+	RT_CHECK(frame_async_finish(ctx, pf, overflowed));
+	if (ctx->after_frame_queued && !early && !*overflowed) RT_CHECK(ctx->after_frame_queued());
+	return RT_HIP_OK;
 }
 
 
@@ -1983,7 +1992,7 @@ int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float
                      int h, int tile, int rank, int nranks, uint8_t* const* d_rgba, int packed)
 {
 	ctx->last_frame_rays = 0;
-	if (w <= 0 || h <= 0 || nframes <= 0 || ctx->cfg.bounces <= 0) return RT_HIP_OK;
+	if (w <= 0 || h <= 0 || nframes <= 0 || ctx->cfg.bounces <= 0) return ctx->after_frame_queued ? ctx->after_frame_queued() : RT_HIP_OK;
 	if (nframes > RT_MAX_BATCH) { rt_set_error("more than %d frames in a batch", RT_MAX_BATCH); return RT_HIP_ERR_LIMIT; }
 	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 26) { rt_set_error("frame larger than 2^26 texels"); return RT_HIP_ERR_LIMIT; }
 	if (ctx->cfg.bounces > 8) { rt_set_error("bounces > 8 not supported"); return RT_HIP_ERR_LIMIT; }
@@ -2030,6 +2039,7 @@ int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float
 		}
 	}
 	ctx->last_frame_rays = rays;
+	if (ctx->after_frame_queued) RT_CHECK(ctx->after_frame_queued());
 	return RT_HIP_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -112,6 +113,7 @@ struct PendingFrame {
 	size_t trace_mark = 0;       // trace_events index behind this frame's launches
 	int n0 = 0, bounces = 0, nframes = 0, num_lights = 0;
 	bool shadows = false;
+	bool can_overflow = false;   // some level's bound is the level cap: the frame may have to be redone with host-sized levels
 	int64_t rays = 0;
 	// what a repeat on the synchronous driver needs (a level overflowed its bound)
 	FrameSet fs;
@@ -204,6 +206,10 @@ struct rt_hip_ctx {
 	int comm_rank = 0, comm_nranks = 1;
 	int mg_key[4] = {0, 0, 0, 0}; // (w, h, tile, nranks) the send chunk was cleared for
 	DevBuf d_mg_send, d_mg_recv, d_mg_counts, d_mg_photons;
+
+	// rt_render_frames: work to queue behind the frame's kernels BEFORE the host waits for its counters (the multi-GPU entry
+	// puts its all-gather and unpack there: one host wait per frame instead of two); run again if the frame had to be redone
+	std::function<int()> after_frame_queued;
 
 	int last_count = 0;
 	int64_t last_frame_rays = 0;
