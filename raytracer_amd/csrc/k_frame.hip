@@ -861,8 +861,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 
 			Hit best;
 			blocked = brute_trace<true>(sv, O, L, best);
 		}
-		// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116)
-		if (blocked && 0.0f < norm3(L)) atomicOr(&occl[i], 1u << light);
+		// `distance < L.norm()` with distance == 0 (rt_raytracer.cpp:115-116).  0 < sqrt(x) <=> 0 < x for the correctly rounded square
+		// root (denormals included; NaN fails both), so the test is made on the squared length
+		if (blocked && 0.0f < dot3(L, L)) atomicOr(&occl[i], 1u << light);
 	});
 	if (CENSUS && census) census_add(census, cn, ct, rays);
 }
