@@ -8,7 +8,7 @@ for r in rows:
     seq.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), m.group(1) if m else r['Kernel_Name'][:20], r.get('Queue_Id')))
 seq.sort()
 idx = [i for i, s in enumerate(seq) if s[2] in ('k_init_spawn', 'k_init_nodes')]
-i0, i1 = idx[-3], idx[-2]
+i0, i1 = idx[len(idx) // 2], idx[len(idx) // 2 + 1]   # a steady-state frame from the middle of the run
 t0 = seq[i0][0]
 prev = None
 for s in seq[i0 - 1:i1]:
