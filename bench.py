@@ -691,6 +691,26 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
     cfg["ms_per_frame_single_median"] = round(float(np.median(ts)), 4)
     cfg["ms_per_frame_single_p95"] = round(float(np.percentile(ts, 95)), 4)
     cfg["single_frame_note"] = "one frame per call with a stream sync after each (latency of a lone frame), median and 95th percentile of 20"
+    # The timed region runs with config.profile = 1 (every k_shadow launch is timed through its dispatch packet, which is what the
+    # roofline object needs); the same pipelined loop without it, for what a caller that does not time kernels gets
+    try:
+        enq = type(g).frame_enqueue_device.__wrapped__ if hasattr(type(g).frame_enqueue_device, "__wrapped__") else type(g).frame_enqueue_device
+        def piped(n):
+            enq(g, gb_p, gb_n, W, H, out_dev)
+            for _ in range(n - 1):
+                enq(g, gb_p, gb_n, W, H, out_dev)
+                g.frame_finish()
+            g.frame_finish()
+            g.sync()
+        g.set_config(profile=0)
+        piped(30)
+        t0 = time.perf_counter(); piped(300); dt = time.perf_counter() - t0
+        g.set_config(profile=1)
+        cfg["ms_per_frame_without_kernel_timing"] = round(dt / 300 * 1e3, 4)
+        cfg["without_kernel_timing_note"] = "the timed region's loop (rt_hip_frame_enqueue_device / rt_hip_frame_finish, one frame queued ahead), 300 frames, config.profile = 0; never `value`"
+    except Exception as e:
+        g.set_config(profile=1)
+        cfg["without_kernel_timing_note"] = "not measured: %r" % (e,)
     # The frame with the scene brought up to date first, on a context that applies model matrices as processRays does
     # (use_model_mat = 1; the scene's matrices are identities, so the geometry and the image are the same).
     render = type(g).render_tiles_batch_device.__wrapped__
