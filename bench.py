@@ -118,6 +118,10 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=1,
                     help="N = 1 only: frames in flight = contexts (each its own stream) fed from as many host threads; the "
                          "default 1 keeps the kernels of a frame alone on the GPU, which is what the roofline object measures")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frames the library's pipeline keeps in flight on streams of their own (tuning.frame_streams, 1..4). 0 = auto: 1 at N = 1 "
+                         "(launches that do not overlap, which is what the roofline object prices), 3 for a frame split over N > 1 GPUs "
+                         "through the C ABI (rt_hip_frame_multi_enqueue_device)")
     ap.add_argument("--tuning", default="", help="rt_hip_tuning overrides, name=value,name=value (variant measurements; results never depend on them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -235,6 +239,11 @@ def main():
     # the library's own RCCL route needs one GPU per rank; the gloo rehearsal (all ranks on device 0) takes the torch route
     cabi = strong and world > 1 and args.route == "cabi" and backend == "nccl"
     K = args.frames_per_step if args.frames_per_step > 0 else (2 if args.photons > 0 else 300)
+    # frames in flight inside ONE context (tuning.frame_streams): the tail of one frame's launches is filled by the next frame's waves
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else (3 if cabi and args.photons == 0 else 1)
+    fif = max(1, min(4, fif)) if args.photons == 0 else 1
+    if fif > 1:
+        g.set_tuning(frame_streams=fif)
 
     # ---- inputs resident in HBM: one G-buffer per frame of a sub-step -------------------------
     nframes = 1 if (strong or world == 1) else world
@@ -260,6 +269,10 @@ def main():
 
     render_batch = rt.RtHip.render_tiles_batch_device.__wrapped__
     render_multi = rt.RtHip.render_frame_multi_device.__wrapped__
+    enqueue_multi = rt.RtHip.frame_multi_enqueue_device.__wrapped__
+    outs_fif = [tiles[0]] + [torch.zeros(npix * 4, dtype=torch.uint8, device=dev) for _ in range(fif - 1)]   # one image per frame in flight
+    if cabi and fif > 1:
+        frame = outs_fif[0]
 
     def substep():
         # this rank's tiles of all the sub-step's frames in one wavefront (a batch of one at N = 1)
@@ -325,15 +338,30 @@ def main():
     enqueue = rt.RtHip.frame_enqueue_device.__wrapped__
 
     def run_steps(count):
+        if cabi and fif > 1:
+            # the split frame through the library's pipeline: up to `fif` frames queued (their shares side by side on this GPU, the
+            # all-gather of one under the kernels of the next), finished oldest first -- every rank in the same order
+            total, rays, pend = count * K, 0, 0
+            for k in range(total):
+                if pend == fif:
+                    rays += g.frame_finish(); pend -= 1
+                enqueue_multi(g, gb_p[0], gb_n[0], W, H, 64, outs_fif[k % fif]); pend += 1
+            while pend:
+                rays += g.frame_finish(); pend -= 1
+            return rays
         if not extra and pipelined:
             total, rays = count * K, 0
             if total == 0:
                 return 0
-            enqueue(g, gb_p[0], gb_n[0], W, H, tiles[0])
-            for _ in range(total - 1):
-                enqueue(g, gb_p[0], gb_n[0], W, H, tiles[0])
-                rays += g.frame_finish()
-            return rays + g.frame_finish()
+            ahead = max(2, fif) - 1 if fif > 1 else 1    # frames queued ahead of the one being finished
+            pend = 0
+            for k in range(total):
+                if pend > ahead:
+                    rays += g.frame_finish(); pend -= 1
+                enqueue(g, gb_p[0], gb_n[0], W, H, outs_fif[k % fif]); pend += 1
+            while pend:
+                rays += g.frame_finish(); pend -= 1
+            return rays
         if not extra:
             return sum(step() for _ in range(count))
         import threading
@@ -375,6 +403,15 @@ def main():
     substeps = args.steps * K
     frames_done = substeps * nframes
 
+    lone_latency = None
+    if cabi and fif > 1:
+        # latency of ONE split frame (nothing else in flight), untimed: 10 calls of the blocking entry
+        render_multi(g, gb_p[0], gb_n[0], W, H, 64, frame)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            render_multi(g, gb_p[0], gb_n[0], W, H, 64, frame)
+        lone_latency = (time.perf_counter() - t1) / 10 * 1e3
     # ---- roofline of the dominant kernel (rank 0's launches) --------------------------------
     roofline = build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong)
 
@@ -389,7 +426,7 @@ def main():
 
     # ---- untimed extras on rank 0 at N = 1: the spans SURVEY 8d defines around the device-resident frame ----
     extras, target, more = {}, None, {}
-    if rank == 0 and world == 1 and not args.no_extras and args.photons == 0 and inflight == 1:
+    if rank == 0 and world == 1 and not args.no_extras and args.photons == 0 and inflight == 1 and fif == 1:
         extras, target = run_extras(args, rt, scenes, g, scene, gb_p[0], gb_n[0], W, H, dev, dev_index, ACCEL)
         more = run_more_configs(args, rt, scenes, g, scene, gb_p[0], gb_n[0], W, H, dev, dev_index, ACCEL, elapsed / frames_done * 1e3)
 
@@ -409,7 +446,7 @@ def main():
 
     if rank == 0:
         ms_per_frame = elapsed / frames_done * 1e3
-        latency = elapsed / substeps * 1e3
+        latency = lone_latency if lone_latency is not None else elapsed / substeps * 1e3 * (fif if (fif > 1 and world == 1) else 1)
         out = {
             "metric": "secondary Mrays/s", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -421,6 +458,8 @@ def main():
                        "shadows": args.shadow_mode, "accel": args.accel, "parallelism": "tiles x%d" % world,
                        **({"tuning": tuning} if tuning else {}),
                        **({"frames_in_flight": inflight} if inflight > 1 else {}),
+                       **({"frames_in_flight": fif, "frames_in_flight_note": "tuning.frame_streams: that many frames of the library's pipeline run side by side on "
+                           "streams of their own; a k_shadow launch then shares the GPU with another frame's, so avg_launch_ms is not the launch's own cost"} if fif > 1 else {}),
                        **({"frame_pipeline": "rt_hip_frame_enqueue_device / rt_hip_frame_finish, one frame queued ahead"} if (pipelined and inflight == 1) else {}),
                        "rays_per_frame": round(total_rays / frames_done, 1),
                        "ms_per_frame": round(ms_per_frame, 4),
@@ -432,8 +471,9 @@ def main():
                        "timed_region_s": round(elapsed, 3),
                        "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"],
                        **extras,
-                       **({"multi_gpu_route": ("C ABI: rt_hip_comm_init (id broadcast over torch.distributed) + rt_hip_render_frame_multi_device: RCCL "
-                                               "all-gather of the packed tiles inside the library, every rank holds the whole frame" if cabi else
+                       **({"multi_gpu_route": ("C ABI: rt_hip_comm_init (id broadcast over torch.distributed) + " +
+                                               ("rt_hip_frame_multi_enqueue_device / rt_hip_frame_finish, %d frames in flight: " % fif if fif > 1 else "rt_hip_render_frame_multi_device: ") +
+                                               "RCCL all-gather of the packed tiles inside the library, every rank holds the whole frame" if cabi else
                                                "torch.distributed: raytracer_amd/frames.py"),
                            "exchange": ("all-gather of packed tiles after every frame" if strong else
                                         "all-to-all of packed tiles, overlapped with the next sub-step") if os.environ.get("BENCH_XCHG") is None else os.environ["BENCH_XCHG"],
@@ -711,6 +751,31 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
     except Exception as e:
         g.set_config(profile=1)
         cfg["without_kernel_timing_note"] = "not measured: %r" % (e,)
+    # tuning.frame_streams = 2, 3: frames of the pipeline on streams of their own, side by side (throughput, not `value`: the headline
+    # line keeps launches that do not overlap, which is what its roofline object prices)
+    try:
+        enq = type(g).frame_enqueue_device.__wrapped__ if hasattr(type(g).frame_enqueue_device, "__wrapped__") else type(g).frame_enqueue_device
+        outs = [out_dev] + [torch.zeros(npix * 4, dtype=torch.uint8, device=dev) for _ in range(2)]
+        for lanes in (2, 3):
+            g.set_tuning(frame_streams=lanes)
+            def piped(n):
+                pend = 0
+                for i in range(n):
+                    if pend == lanes:
+                        g.frame_finish(); pend -= 1
+                    enq(g, gb_p, gb_n, W, H, outs[i % lanes]); pend += 1
+                while pend:
+                    g.frame_finish(); pend -= 1
+                g.sync()
+            piped(30)
+            t0 = time.perf_counter(); piped(300); dt = time.perf_counter() - t0
+            cfg["ms_per_frame_%d_in_flight" % lanes] = round(dt / 300 * 1e3, 4)
+        g.set_tuning(frame_streams=1)
+        cfg["in_flight_note"] = ("tuning.frame_streams = 2 / 3: enqueued frames are dealt to that many streams (level arrays of their own) and run side by side, "
+                                 "300 frames, with kernel timing on; throughput of a frame loop, never `value`")
+    except Exception as e:
+        g.set_tuning(frame_streams=1)
+        cfg["in_flight_note"] = "not measured: %r" % (e,)
     # The frame with the scene brought up to date first, on a context that applies model matrices as processRays does
     # (use_model_mat = 1; the scene's matrices are identities, so the geometry and the image are the same).
     render = type(g).render_tiles_batch_device.__wrapped__
@@ -841,6 +906,30 @@ def _strong_share(rt, torch, g, d_p, d_n, w, h, whole_ms, reps=6):
         slow = max(per_rank)
         out[str(n)] = {"slowest_rank_ms": round(slow, 4), "fastest_rank_ms": round(min(per_rank), 4), "unpack_ms": round(un, 4),
                        "implied_efficiency": round(whole_ms / (n * (slow + un)), 3), "all_gather_bytes_per_rank": int(chunk)}
+        # the same share with three frames in flight (tuning.frame_streams = 3, rt_hip_tiles_packed_enqueue_device: what
+        # rt_hip_frame_multi_enqueue_device queues per frame before its all-gather): wall time per frame of the slowest rank
+        try:
+            r = per_rank.index(slow)
+            enq = type(g).tiles_packed_enqueue_device.__wrapped__
+            dsts = [torch.zeros(chunk, dtype=torch.uint8, device=d_p.device) for _ in range(3)]
+            g.set_tuning(frame_streams=3)
+            def piped(k):
+                pend = 0
+                for i in range(k):
+                    if pend == 3:
+                        g.frame_finish(); pend -= 1
+                    enq(g, d_p, d_n, w, h, 64, r, n, dsts[i % 3]); pend += 1
+                while pend:
+                    g.frame_finish(); pend -= 1
+                g.sync()
+            piped(6)
+            t0 = time.perf_counter(); piped(10 * reps); dt = (time.perf_counter() - t0) / (10 * reps) * 1e3
+            g.set_tuning(frame_streams=1)
+            out[str(n)]["slowest_rank_ms_3_in_flight"] = round(dt, 4)
+            out[str(n)]["implied_efficiency_3_in_flight"] = round(whole_ms / (n * (dt + un)), 3)
+        except Exception as e:
+            g.set_tuning(frame_streams=1)
+            out[str(n)]["in_flight_error"] = repr(e)
     return out
 
 

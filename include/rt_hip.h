@@ -164,7 +164,12 @@ typedef struct rt_hip_tuning {
 	int shadow_prefix_min_rays; /* -1  RT_HIP_SHADOW_PREFIX_MIN_RAYS: level-0 shadow rays (nodes x lights) from which the shared descent is used; -1 = six
 	                                 times the device's resident threads (below that the shadow launches are as long as their slowest wave and the
 	                                 walks cost more than they save); 0 = always */
-	int reserved[3];
+	int frame_streams;        /* 1    RT_HIP_FRAME_STREAMS: HIP streams the frame pipeline (rt_hip_frame_enqueue*) deals its frames to, each with level
+	                                 arrays of its own (1..4).  1: enqueued frames run one after the other.  More: up to that many frames run side by
+	                                 side, so the tail of one frame's launches and the gaps between them are filled by another frame's waves -- what a
+	                                 job that cares for frames per second rather than for the latency of one frame wants, and what makes a frame that is
+	                                 split over several GPUs (short launches, each as long as its slowest wave) scale */
+	int reserved[2];
 } rt_hip_tuning;
 
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent
@@ -355,6 +360,11 @@ int rt_hip_render_tiles_batch_device(rt_hip_ctx* ctx, const float* const* d_gbuf
 int rt_hip_render_tiles_packed_device(rt_hip_ctx* ctx, const float* const* d_gbuf_pos_rgb,
                                       const float* const* d_gbuf_nrm_rgba, int nframes, int width, int height,
                                       int tile, int rank, int nranks, uint8_t* const* d_packed_out);
+/* One frame's packed share queued without waiting -- rt_hip_render_tiles_packed_device for one frame in the frame pipeline
+ * (rt_hip_frame_enqueue_device's rules: at most max(2, tuning.frame_streams) unfinished, rt_hip_frame_finish completes the
+ * oldest), for a host that runs its own exchange of the chunks.  No counterpart in the reference. */
+int rt_hip_tiles_packed_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width, int height,
+                                       int tile, int rank, int nranks, uint8_t* d_packed_out);
 int rt_hip_unpack_chunks_device(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int width, int height,
                                 int tile, int nranks, uint8_t* d_frame_rgba);
 /* Tile gather without moving empty pixels (collective #2): pack the tiles listed in
@@ -370,7 +380,7 @@ int rt_hip_unpack_tiles_device(rt_hip_ctx* ctx, const uint8_t* d_packed, int wid
                                const int* d_tile_list, int ntiles, uint8_t* d_frame_rgba);
 /* The same frame as rt_hip_render_frame_device, in a pipeline: rt_hip_frame_enqueue_device queues all of the frame's kernels
  * and returns WITHOUT waiting; rt_hip_frame_finish waits for the OLDEST enqueued frame (its image is then complete) and
- * returns its secondary-ray count.  At most two frames may be enqueued and unfinished; with one enqueued ahead the host's
+ * returns its secondary-ray count.  At most two frames (max(2, tuning.frame_streams), up to four) may be enqueued and unfinished; with one enqueued ahead the host's
  * per-frame work runs under the previous frame's kernels.  Frames are executed in order on the context's stream; the other
  * frame entries (rt_hip_render_frame*, rt_hip_render_tiles*) refuse to run while frames are enqueued (RT_HIP_ERR_STATE).  Frames the sync-free driver
  * does not take (photon map, > 30 lights, too large) are rendered inside the enqueue call.  No counterpart in the reference,
@@ -499,6 +509,16 @@ int rt_hip_comm_destroy(rt_hip_ctx* ctx);   /* also done by rt_hip_destroy */
  * rt_hip_last_frame_rays() = this rank's rays. */
 int rt_hip_render_frame_multi_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
                                      int height, int tile, uint8_t* d_rgba_out);
+/* The same, queued without waiting: the frame pipeline's form of it (no counterpart in the reference, whose Scene::draw renders
+ * one frame at a time, data/scene.cpp:40-58).  rt_hip_frame_finish completes the oldest enqueued frame: on return its assembled
+ * image is in d_rgba_out on this rank.  At most max(2, tuning.frame_streams) frames may be unfinished; with frame_streams > 1 the
+ * ranks' shares of consecutive frames run side by side on each GPU, and the all-gather of frame k travels under the kernels of
+ * frame k + 1 -- the form to use when frames per second matter: an eighth of a 1080p frame is three launches of ~90 us that
+ * leave most of the GPU idle, three frames in flight fill it (0.33 -> 0.15 ms per share measured on one GPU).  Every rank must
+ * enqueue and finish the same frames in the same order.  Frames too large for the sync-free driver are refused (RT_HIP_ERR_LIMIT):
+ * rt_hip_render_frame_multi_device takes those. */
+int rt_hip_frame_multi_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
+                                      int height, int tile, uint8_t* d_rgba_out);
 /* PhotonMap::generate over all ranks (collective): each rank emits its contiguous range of the global photon index
  * sequence, the shards are all-gathered in rank (= index) order, and every rank installs the full set -- the
  * photon array rt_hip_photon_generate makes on one GPU, bit for bit.  *out_stored = photons in the map. */

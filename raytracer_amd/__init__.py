@@ -61,7 +61,7 @@ class Tuning(C.Structure):
     """rt_hip_tuning (include/rt_hip.h): knobs outside the reference's semantics."""
     _fields_ = [("lds_stack_depth", C.c_int), ("xcd_chunk", C.c_int), ("trace_oversub", C.c_int), ("auto_accel", C.c_int),
                 ("ploc_radius", C.c_int), ("frame_sync", C.c_int), ("gather_heavy", C.c_uint32), ("extra_lds_bytes", C.c_int),
-                ("max_bvh_depth", C.c_int), ("refit_max_growth", C.c_float), ("gather_fine", C.c_int), ("gather_xcd_chunk", C.c_int), ("gather_fine_cells", C.c_int), ("gather_medium", C.c_uint32), ("shadow_prefix", C.c_int), ("shadow_prefix_steps", C.c_int), ("shadow_prefix_min_rays", C.c_int), ("reserved", C.c_int * 3)]
+                ("max_bvh_depth", C.c_int), ("refit_max_growth", C.c_float), ("gather_fine", C.c_int), ("gather_xcd_chunk", C.c_int), ("gather_fine_cells", C.c_int), ("gather_medium", C.c_uint32), ("shadow_prefix", C.c_int), ("shadow_prefix_steps", C.c_int), ("shadow_prefix_min_rays", C.c_int), ("frame_streams", C.c_int), ("reserved", C.c_int * 2)]
 
 
 UPDATE_NONE, UPDATE_TABLES, UPDATE_REFIT, UPDATE_REBUILD = 0, 1, 2, 3
@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device", "rt_hip_gbuffer_select_noalloc_device",
-    "rt_hip_frame_enqueue_device", "rt_hip_frame_enqueue", "rt_hip_frame_enqueue_g16", "rt_hip_frame_finish", "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device",
+    "rt_hip_frame_enqueue_device", "rt_hip_frame_enqueue", "rt_hip_frame_enqueue_g16", "rt_hip_frame_finish", "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device", "rt_hip_frame_multi_enqueue_device", "rt_hip_tiles_packed_enqueue_device",
     "rt_hip_photon_generate_multi", "rt_hip_set_model_mats", "rt_hip_photon_generate", "rt_hip_photon_get", "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
 ]
 
@@ -175,6 +175,8 @@ def load_library() -> C.CDLL:
     L.rt_hip_comm_init.argtypes = [P, P, C.c_int, C.c_int]
     L.rt_hip_comm_destroy.argtypes = [P]
     L.rt_hip_render_frame_multi_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_frame_multi_enqueue_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_tiles_packed_enqueue_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_photon_generate_multi.argtypes = [P, C.c_int, C.POINTER(C.c_int64)]
     L.rt_hip_get_tuning.argtypes = [P, C.POINTER(Tuning)]
     L.rt_hip_set_tuning.argtypes = [P, C.POINTER(Tuning)]
@@ -552,6 +554,14 @@ class RtHip:
 
     def render_frame_multi_device(self, d_pos_rgb, d_nrm_rgba, w, h, tile, d_rgba):
         self._ck(self.lib.rt_hip_render_frame_multi_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, tile, _dptr(d_rgba)))
+
+    def frame_multi_enqueue_device(self, d_pos_rgb, d_nrm_rgba, w, h, tile, d_rgba):
+        """rt_hip_frame_multi_enqueue_device: the split frame queued without waiting; frame_finish() completes the oldest."""
+        self._ck(self.lib.rt_hip_frame_multi_enqueue_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, tile, _dptr(d_rgba)))
+
+    def tiles_packed_enqueue_device(self, d_pos_rgb, d_nrm_rgba, w, h, tile, rank, nranks, d_packed):
+        """rt_hip_tiles_packed_enqueue_device: one frame's packed share queued without waiting; frame_finish() completes the oldest."""
+        self._ck(self.lib.rt_hip_tiles_packed_enqueue_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, tile, rank, nranks, _dptr(d_packed)))
 
     def photon_generate_multi(self, per_light):
         stored = C.c_int64(0)

@@ -510,13 +510,15 @@ __device__ __forceinline__ int level0_pixel(const FrameSet& fs, int jj, int w, i
 // lanes -- the descent from the root to the neighbourhood of the origins, 64 times the same box tests.  That descent is
 // made once per (8x8 tile of level 0, light) by ONE lane of a small kernel, against the group as a whole:
 //   * the group's origins and direction vectors are bounded by boxes (k_init_spawn, group_box_store);
-//   * from the root down, while one child box holds all origins: step into that child, and keep its sibling unless
-//     NO ray of the group can cross the sibling's box (interval form of the slab test: every origin in the origin box,
-//     every direction in the direction box -- a superset of the group's rays);
-//   * the record = where the descent stopped (entry) + the kept siblings in stack order.
-// k_shadow then starts each ray of the group at `entry` with the siblings already on its stack.  The traversal only ever
-// visits MORE than the per-ray descent would (a sibling is dropped only when it is missed by every ray), so the any-hit
-// result of every ray is what it was (tests: frames bit-identical with tuning.shadow_prefix = 0 and > 0).
+//   * a child box is classified against the group by the interval form of the slab test (every origin in the origin box,
+//     every direction in the direction box -- a superset of the group's rays): missed by ALL rays, hit by ALL, or mixed;
+//   * the walk (k_shadow_prefix) is the traversal every ray of the group would make, for as long as that is decidable:
+//     step into a child all rays hit, keep the other child on the stack unless all rays miss it, pop when both are
+//     missed, stop before stepping into a mixed box;
+//   * the record = where the walk stopped (entry) + its stack.
+// k_shadow then starts each ray of the group at `entry` with that stack.  A subtree is dropped only when it is missed by
+// every ray of the group, so a ray visits at least what it would have visited by itself and its any-hit result is what it
+// was (tests: frames bit-identical with tuning.shadow_prefix = 0 and > 0, and against the oracle).
 struct GroupBox {  // 48 B; omin[0] > omax[0]: the group has no active node
 	float omin[3], omax[3];  // origins O = V + 0.1 N
 	float vmin[3], vmax[3];  // node positions V (direction = light - V)
@@ -1381,8 +1383,9 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_chunks(const uint32_t* __restr
 
 // ================================================================================================
 int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int w, int h, int tile, int nranks,
-                     uint8_t* d_frame)
+                     uint8_t* d_frame, hipStream_t st)
 {
+	if (!st) st = ctx->stream;
 	const int key[4] = {w, h, tile, nranks};
 	const int tiles_x = (w + tile - 1) / tile, tiles_y = (h + tile - 1) / tile;
 	if (memcmp(key, ctx->all_tiles_key, sizeof(key)) != 0 || !ctx->d_all_tiles.p) {
@@ -1408,7 +1411,7 @@ int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_byt
 		return RT_HIP_ERR_ARG;
 	}
 	const int64_t n = chunk_pixels * nranks;
-	hipLaunchKernelGGL(k_unpack_chunks, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ctx->stream,
+	hipLaunchKernelGGL(k_unpack_chunks, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
 	                   (const uint32_t*)d_chunks, chunk_pixels, nranks, cl, ctx->d_all_tiles.as<int>(), w, h, tile, (uint32_t*)d_frame);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
@@ -1724,13 +1727,40 @@ static int owned_tile_list(rt_hip_ctx* ctx, int w, int h, int tile, int rank, in
 	return RT_HIP_OK;
 }
 
+// Lane `lane` of the frame pipeline: its stream (created on first use; lane 0 = the context's) and its level arrays.
+FrameLane rt_frame_lane(rt_hip_ctx* ctx, int lane)
+{
+	FrameLane l;
+	l.index = lane;
+	if (lane == 0) {
+		l.stream = ctx->stream;
+		l.nodes_a = &ctx->d_nodes_a; l.nodes_b = &ctx->d_nodes_b; l.gate = &ctx->d_gate; l.node_inc = &ctx->d_node_inc; l.node_uv = &ctx->d_node_uv;
+		l.rays_q = &ctx->d_rays_q; l.ray_parent = &ctx->d_ray_parent; l.records = &ctx->d_records; l.hits = &ctx->d_hits; l.occ = &ctx->d_occ;
+		l.child_slot = &ctx->d_child_slot; l.fcount = &ctx->d_fcount; l.group_boxes = &ctx->d_group_boxes; l.prefix = &ctx->d_prefix;
+		l.fcount_clean = &ctx->fcount_clean; l.fcount_clean_n = &ctx->fcount_clean_n;
+		return l;
+	}
+	if (!ctx->lane_stream[lane] && hipStreamCreateWithFlags(&ctx->lane_stream[lane], hipStreamNonBlocking) != hipSuccess) ctx->lane_stream[lane] = nullptr;
+	FrameBufs& b = ctx->lane_bufs[lane];
+	l.stream = ctx->lane_stream[lane] ? ctx->lane_stream[lane] : ctx->stream;  // (no stream to be had: the lane shares the context's; still correct)
+	l.nodes_a = &b.nodes_a; l.nodes_b = &b.nodes_b; l.gate = &b.gate; l.node_inc = &b.node_inc; l.node_uv = &b.node_uv;
+	l.rays_q = &b.rays_q; l.ray_parent = &b.ray_parent; l.records = &b.records; l.hits = &b.hits; l.occ = &b.occ;
+	l.child_slot = &b.child_slot; l.fcount = &b.fcount; l.group_boxes = &b.group_boxes; l.prefix = &b.prefix;
+	l.fcount_clean = &ctx->lane_fcount_clean[lane]; l.fcount_clean_n = &ctx->lane_fcount_clean_n[lane];
+	return l;
+}
+
 // Queue every kernel of the frame and the read-back of its counters into pf->h_fc; nothing is waited for.
 static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int tile, int rank, int nranks, PendingFrame* pf,
-                               bool* declined)
+                               bool* declined, int lane_index = 0)
 {
 	*declined = true;
-	hipStream_t st = ctx->stream;
+	const FrameLane ln = rt_frame_lane(ctx, lane_index);
+	hipStream_t st = ln.stream;
+	pf->stream = st;
 	SceneView sv = rt_scene_view(ctx);
+	// the HBM part of the traversal stacks: a set of columns per lane (frames of different lanes trace at the same time)
+	if (sv.spill && sv.stack_depth > sv.lds_depth) sv.spill += (size_t)lane_index * (size_t)(sv.stack_depth - sv.lds_depth) * sv.spill_stride;
 	const int bounces = ctx->cfg.bounces;
 	const int packed = fs.packed;
 	fs.tile_list = nullptr; fs.ntiles = 0; fs.packed = 0;
@@ -1756,27 +1786,27 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	pf->can_overflow = false;  // a level whose bound is the cap rather than twice its parent's can come out larger than its arrays
 	for (int L = 1; L < bounces; ++L) pf->can_overflow = pf->can_overflow || cap[L] < 2 * cap[L - 1];
 	const int64_t maxcap = *std::max_element(cap.begin(), cap.end());
-	RT_CHECK(ctx->d_nodes_a.reserve((size_t)off[bounces] * sizeof(NodeGeo)));
-	RT_CHECK(ctx->d_nodes_b.reserve((size_t)off[bounces] * sizeof(NodeShade)));
-	RT_CHECK(ctx->d_gate.reserve((size_t)off[bounces] * sizeof(int)));
-	RT_CHECK(ctx->d_node_inc.reserve((size_t)off[bounces] * 12));  // incident directions, 3 floats per node
-	float* const inc_base = ctx->d_node_inc.as<float>();
-	if (sv.tex) RT_CHECK(ctx->d_node_uv.reserve((size_t)off[bounces] * 8));  // textured scenes: a texcoord per node
-	float* const uv_base = sv.tex ? ctx->d_node_uv.as<float>() : nullptr;
+	RT_CHECK(ln.nodes_a->reserve((size_t)off[bounces] * sizeof(NodeGeo)));
+	RT_CHECK(ln.nodes_b->reserve((size_t)off[bounces] * sizeof(NodeShade)));
+	RT_CHECK(ln.gate->reserve((size_t)off[bounces] * sizeof(int)));
+	RT_CHECK(ln.node_inc->reserve((size_t)off[bounces] * 12));  // incident directions, 3 floats per node
+	float* const inc_base = ln.node_inc->as<float>();
+	if (sv.tex) RT_CHECK(ln.node_uv->reserve((size_t)off[bounces] * 8));  // textured scenes: a texcoord per node
+	float* const uv_base = sv.tex ? ln.node_uv->as<float>() : nullptr;
 	auto level_uv = [&](int L) -> float* { return uv_base ? uv_base + 2 * (size_t)off[L] : nullptr; };
-	RT_CHECK(ctx->d_rays_q.reserve((size_t)maxcap * 24));
-	RT_CHECK(ctx->d_ray_parent.reserve((size_t)maxcap * 4));
-	RT_CHECK(ctx->d_records.reserve((size_t)maxcap * sizeof(HitInfo)));
-	RT_CHECK(ctx->d_hits.reserve((size_t)maxcap * sizeof(Hit)));
+	RT_CHECK(ln.rays_q->reserve((size_t)maxcap * 24));
+	RT_CHECK(ln.ray_parent->reserve((size_t)maxcap * 4));
+	RT_CHECK(ln.records->reserve((size_t)maxcap * sizeof(HitInfo)));
+	RT_CHECK(ln.hits->reserve((size_t)maxcap * sizeof(Hit)));
 	// frame counters: [0] active level-0 nodes, [1] overflow flag,
 	// [8 + 8L + 0] nodes of level L, [.. + 1] reflection rays of level L, [.. + 2] refraction rays
 	const int nfc = 8 + 8 * (bounces + 1);
-	RT_CHECK(ctx->d_fcount.reserve((size_t)nfc * 4));  // this driver's own: nothing else writes to it
-	int* fc = ctx->d_fcount.as<int>();
-	float* q_org = ctx->d_rays_q.as<float>();
+	RT_CHECK(ln.fcount->reserve((size_t)nfc * 4));  // this driver's own: nothing else writes to it
+	int* fc = ln.fcount->as<int>();
+	float* q_org = ln.rays_q->as<float>();
 	float* q_dir = q_org + (size_t)maxcap * 3;
-	int* q_parent = ctx->d_ray_parent.as<int>();
-	HitInfo* d_hi = ctx->d_records.as<HitInfo>();
+	int* q_parent = ln.ray_parent->as<int>();
+	HitInfo* d_hi = ln.records->as<HitInfo>();
 	const bool shadows = !ctx->cfg.use_photon_map && ctx->cfg.do_shadows && sv.num_lights > 0;
 
 	// Order of a level: spawn the reflection rays; launch A = reflection queue + the shadow rays of
@@ -1784,8 +1814,8 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	// hits, Q9); launch B = refraction queue + the shadow rays of the other lights; children.  The
 	// light term needs all shadow rays of the level, so it is evaluated in k_combine at the end.
 	const bool fuse = shadows && !(sv.num_spheres > 0 && sv.num_tris == 0);
-	RT_CHECK(ctx->d_occ.reserve((size_t)off[bounces] * 4));  // shadow masks and child flags
-	RT_CHECK(ctx->d_child_slot.reserve((size_t)off[bounces] * 8));  // [node][branch] -> child index (k_combine's pull form)
+	RT_CHECK(ln.occ->reserve((size_t)off[bounces] * 4));  // shadow masks and child flags
+	RT_CHECK(ln.child_slot->reserve((size_t)off[bounces] * 8));  // [node][branch] -> child index (k_combine's pull form)
 	// The shared descent of every (group of 64 nodes, light) of a level (k_shadow_prefix): tuning.shadow_prefix = the most
 	// siblings a record may carry (they start on the rays' LDS stacks), 0 = every ray descends from the root by itself.
 	const int max_push = std::min(ctx->tuning.shadow_prefix, PREFIX_MAX);
@@ -1799,17 +1829,17 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	// nodes of them lie too far apart for a shared descent (measured: the level-1 launch 235 -> 232 us for 35 us of walks).
 	const int64_t groups0 = ((int64_t)n0 + 63) / 64;
 	if (use_prefix) {
-		RT_CHECK(ctx->d_group_boxes.reserve((size_t)groups0 * sizeof(GroupBox)));
-		RT_CHECK(ctx->d_prefix.reserve((size_t)groups0 * sv.num_lights * PREFIX_INTS * sizeof(int)));
+		RT_CHECK(ln.group_boxes->reserve((size_t)groups0 * sizeof(GroupBox)));
+		RT_CHECK(ln.prefix->reserve((size_t)groups0 * sv.num_lights * PREFIX_INTS * sizeof(int)));
 	}
-	auto level_prefix = [&](int L) -> int* { return (use_prefix && L == 0) ? ctx->d_prefix.as<int>() : nullptr; };
+	auto level_prefix = [&](int L) -> int* { return (use_prefix && L == 0) ? ln.prefix->as<int>() : nullptr; };
 	auto prefix_launch = [&](int L, int n) -> int {
 		if (!use_prefix || L != 0) return RT_HIP_OK;
 		// (the groups' boxes: k_init_spawn)
 		hipEvent_t t0, t1;  // (profile mode: its time is booked with the shadow launches it serves)
 		RT_CHECK(rt_next_trace_events(ctx, 3, &t0, &t1));
 		hipExtLaunchKernelGGL(k_shadow_prefix, dim3(nblocks(groups0 * sv.num_lights, BLOCK)), dim3(BLOCK), 0, st, t0, t1, 0u, sv,
-		                      (const GroupBox*)ctx->d_group_boxes.as<GroupBox>(), n, (const int*)nullptr, sv.num_lights, ctx->cfg.shadow_t_max,
+		                      (const GroupBox*)ln.group_boxes->as<GroupBox>(), n, (const int*)nullptr, sv.num_lights, ctx->cfg.shadow_t_max,
 		                      max_push, ctx->tuning.shadow_prefix_steps, level_prefix(0));
 		RT_HIP_CHECK(hipGetLastError());
 		return RT_HIP_OK;
@@ -1820,7 +1850,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		unsigned long long* cen = rt_census_ptr(ctx, 1);
 		if (q_count) {
 			fq.org = q_org; fq.dir = q_dir; fq.count_ptr = q_count; fq.capacity = n;
-			fq.hits = ctx->d_hits.as<Hit>(); fq.census = rt_census_ptr(ctx, 0);
+			fq.hits = ln.hits->as<Hit>(); fq.census = rt_census_ptr(ctx, 0);
 		}
 		if (hi <= lo && !q_count) return RT_HIP_OK;
 		const size_t lds = rt_trace_lds(sv, TRACE_BLOCK);
@@ -1843,22 +1873,22 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	RT_HIP_CHECK(hipEventRecord(pf->ev0, st));
 	// The counters are zeroed at the END of a frame, behind its read-back, for the frame that follows: the
 	// first thing a frame queues is then its first kernel, not a fill and the host time after it.
-	if (ctx->fcount_clean != fc || ctx->fcount_clean_n < nfc) RT_HIP_CHECK(hipMemsetAsync(fc, 0, (size_t)nfc * 4, st));
-	ctx->fcount_clean = nullptr;
+	if ((*ln.fcount_clean) != fc || (*ln.fcount_clean_n) < nfc) RT_HIP_CHECK(hipMemsetAsync(fc, 0, (size_t)nfc * 4, st));
+	(*ln.fcount_clean) = nullptr;
 	for (int L = 0; L < bounces; ++L) {
 		const int n = (int)cap[L];
 		int* lc = fc + 8 + 8 * L;                      // this level's counters
 		const int* n_ptr = L == 0 ? nullptr : lc;      // level 0's count is known: n0
 		const bool recurse = (L + 1 < bounces);
-		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + off[L];
-		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
-		int* gate = ctx->d_gate.as<int>() + off[L];
-		unsigned int* occl = ctx->d_occ.as<unsigned int>() + off[L];
+		NodeGeo* geo = ln.nodes_a->as<NodeGeo>() + off[L];
+		NodeShade* shade = ln.nodes_b->as<NodeShade>() + off[L];
+		int* gate = ln.gate->as<int>() + off[L];
+		unsigned int* occl = ln.occ->as<unsigned int>() + off[L];
 		if (L == 0) {
 			// nodes, gate, cleared shade / shadow mask and the reflection queue of level 0 in one pass
 			hipLaunchKernelGGL(k_init_spawn, dim3(nblocks(n0, CBLOCK)), dim3(CBLOCK), 0, st, sv, fs, w, h, n0,
 			                   tile, rank, nranks, recurse ? 1 : 0, geo, (float*)nullptr, gate, occl, q_org, q_dir, q_parent, lc + 1, fc + 0, level_uv(0),
-			                   use_prefix ? ctx->d_group_boxes.as<GroupBox>() : (GroupBox*)nullptr);
+			                   use_prefix ? ln.group_boxes->as<GroupBox>() : (GroupBox*)nullptr);
 		} else if (recurse) {
 			// deeper levels: k_make_children has cleared the shadow masks of the nodes it created.  The last
 			// level needs nothing here: no rays to spawn, the light term is k_combine's, NodeShade stays unwritten.
@@ -1875,23 +1905,23 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr, prefix));
 			break;
 		}
-		NodeGeo* child_geo = ctx->d_nodes_a.as<NodeGeo>() + off[L + 1];
-		unsigned int* child_occl = ctx->d_occ.as<unsigned int>() + off[L + 1];
+		NodeGeo* child_geo = ln.nodes_a->as<NodeGeo>() + off[L + 1];
+		unsigned int* child_occl = ln.occ->as<unsigned int>() + off[L + 1];
 		int* child_count = lc + 8;                     // = level L+1's node count
 		const int child_cap = (int)cap[L + 1];
 		const Hit* raw = nullptr;                      // fused: children are made straight from the raw hits
 		if (fuse) {
 			RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl_a, occl, lc + 1, prefix));
-			raw = ctx->d_hits.as<Hit>();
+			raw = ln.hits->as<Hit>();
 		} else {
 			if (shadows) RT_CHECK(shadow_launch(geo, n, n_ptr, 0, nl, occl, nullptr, prefix));
 			RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 1));
 		}
 		// texcoords of the children: from the queue's raw hits (trace_queue leaves them in d_hits for triangles)
-		const Hit* tc_hits = (sv.num_spheres > 0 && sv.num_tris == 0) ? nullptr : ctx->d_hits.as<Hit>();
+		const Hit* tc_hits = (sv.num_spheres > 0 && sv.num_tris == 0) ? nullptr : ln.hits->as<Hit>();
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
 		                   lc + 1, 0, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
-		                   level_uv(L + 1), occl, ctx->d_child_slot.as<int>() + 2 * off[L]);
+		                   level_uv(L + 1), occl, ln.child_slot->as<int>() + 2 * off[L]);
 		// refraction, gated after the reflection hits are known (Q9)
 		hipLaunchKernelGGL(k_spawn_refract, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, geo,
 		                   L == 0 ? (const float*)nullptr : (const float*)(inc_base + 3 * (size_t)off[L]), n, n_ptr, gate, q_org, q_dir, q_parent, lc + 2);
@@ -1900,22 +1930,22 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 		else RT_CHECK(trace_queue(ctx, sv, q_org, q_dir, n, d_hi, lc + 2));
 		hipLaunchKernelGGL(k_make_children, dim3(nblocks(n, CBLOCK)), dim3(CBLOCK), 0, st, sv, d_hi, raw, q_dir, q_parent, n,
 		                   lc + 2, 1, gate, child_geo, inc_base + 3 * (size_t)off[L + 1], child_occl, child_count, child_cap, fc + 1, tc_hits,
-		                   level_uv(L + 1), occl, ctx->d_child_slot.as<int>() + 2 * off[L]);
+		                   level_uv(L + 1), occl, ln.child_slot->as<int>() + 2 * off[L]);
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	// The last level is folded into the combine of the level above it (pull form: a launch, a 5 us gap and a round trip of
 	// the children's colours through NodeShade less); deeper frames chain the remaining levels bottom-up as before.
 	for (int L = bounces >= 2 ? bounces - 2 : 0; L >= 0; --L) {
 		const int* n_ptr = L == 0 ? nullptr : fc + 8 + 8 * L;
-		NodeGeo* geo = ctx->d_nodes_a.as<NodeGeo>() + off[L];
-		NodeShade* shade = ctx->d_nodes_b.as<NodeShade>() + off[L];
-		NodeShade* pshade = L > 0 ? ctx->d_nodes_b.as<NodeShade>() + off[L - 1] : nullptr;
-		const unsigned int* occl = ctx->d_occ.as<unsigned int>() + off[L];
+		NodeGeo* geo = ln.nodes_a->as<NodeGeo>() + off[L];
+		NodeShade* shade = ln.nodes_b->as<NodeShade>() + off[L];
+		NodeShade* pshade = L > 0 ? ln.nodes_b->as<NodeShade>() + off[L - 1] : nullptr;
+		const unsigned int* occl = ln.occ->as<unsigned int>() + off[L];
 		ChildLevel pull = {nullptr, nullptr, nullptr, nullptr};
 		if (bounces >= 2 && L == bounces - 2) {
-			pull.slot = ctx->d_child_slot.as<int>() + 2 * off[L];
-			pull.geo = ctx->d_nodes_a.as<NodeGeo>() + off[L + 1];
-			pull.occl = ctx->d_occ.as<unsigned int>() + off[L + 1];
+			pull.slot = ln.child_slot->as<int>() + 2 * off[L];
+			pull.geo = ln.nodes_a->as<NodeGeo>() + off[L + 1];
+			pull.occl = ln.occ->as<unsigned int>() + off[L + 1];
 			pull.uv = level_uv(L + 1);
 		}
 		hipLaunchKernelGGL(k_combine, dim3(nblocks((int)cap[L], BLOCK)), dim3(BLOCK), 0, st, sv, geo, shade, (int)cap[L], n_ptr, L,
@@ -1926,7 +1956,7 @@ static int frame_async_enqueue(rt_hip_ctx* ctx, FrameSet fs, int w, int h, int t
 	RT_HIP_CHECK(hipEventRecord(pf->ev1, st));
 	hipLaunchKernelGGL(k_zero_ints, dim3(1), dim3(128), 0, st, fc, nfc);  // behind the event: for the next frame
 	RT_HIP_CHECK(hipGetLastError());
-	ctx->fcount_clean = fc; ctx->fcount_clean_n = nfc;
+	(*ln.fcount_clean) = fc; (*ln.fcount_clean_n) = nfc;
 	pf->trace_mark = ctx->trace_events_used;
 	return RT_HIP_OK;
 }
@@ -2233,31 +2263,64 @@ int rt_launch_decode_g16(rt_hip_ctx* ctx, const uint16_t* d_nrm16, const uint16_
 	return RT_HIP_OK;
 }
 
-int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba)
+// The ring slot the next enqueued frame takes.  At most max(2, tuning.frame_streams) frames are unfinished at a time.
+int rt_pipeline_slot(rt_hip_ctx* ctx, int* slot)
 {
-	if (ctx->pending_count >= 2) { rt_set_error("two frames are already enqueued: rt_hip_frame_finish() one first"); return RT_HIP_ERR_STATE; }
+	const int limit = std::max(2, ctx->tuning.frame_streams);
+	if (ctx->pending_count >= limit) { rt_set_error("%d frames are already enqueued: rt_hip_frame_finish() one first", ctx->pending_count); return RT_HIP_ERR_STATE; }
+	*slot = (ctx->pending_head + ctx->pending_count) % RT_MAX_PENDING;
+	return RT_HIP_OK;
+}
+
+int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba, int tile, int rank,
+                     int nranks, int packed)
+{
+	int slot = 0;
+	RT_CHECK(rt_pipeline_slot(ctx, &slot));
 	if (ctx->cfg.bounces <= 0 || ctx->cfg.bounces > 8) { rt_set_error("bounces must be 1..8"); return RT_HIP_ERR_LIMIT; }
 	if ((int)ctx->lights.size() > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
 	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 26) { rt_set_error("frame larger than 2^26 texels"); return RT_HIP_ERR_LIMIT; }
-	PendingFrame* pf = &ctx->pending[(ctx->pending_head + ctx->pending_count) & 1];
+	PendingFrame* pf = &ctx->pending[slot];
 	FrameSet fs;
 	memset(&fs, 0, sizeof(fs));
 	fs.nframes = 1;
+	fs.packed = packed;
 	fs.pos[0] = d_pos_rgb; fs.nrm[0] = d_nrm_rgba; fs.rgba[0] = d_rgba;
 	fs.uv[0] = ctx->frame_uv_count > 0 ? ctx->frame_uv[0] : nullptr;
-	pf->fs = fs; pf->w = w; pf->h = h; pf->tile = 64; pf->rank = 0; pf->nranks = 1; pf->packed = 0;
+	pf->fs = fs; pf->w = w; pf->h = h; pf->tile = tile; pf->rank = rank; pf->nranks = nranks; pf->packed = packed;
+	pf->comm = false;
+	pf->stream = ctx->stream;
 	bool declined = true;
 	const bool can_async = !ctx->cfg.use_photon_map && !ctx->tuning.frame_sync && (int)ctx->lights.size() <= FRAME_ASYNC_MAX_LIGHTS;
-	if (can_async) RT_CHECK(frame_async_enqueue(ctx, fs, w, h, 64, 0, 1, pf, &declined));
+	if (can_async) {
+		// Lanes beyond the first serve the usual frame only (shadow rays on triangles, the closest-hit queues fused into the
+		// shadow launches): the other forms queue trace launches of their own on the context's stream.
+		const bool spheres = ctx->cfg.geometry == RT_HIP_SPHERES;
+		const int lanes = (ctx->cfg.do_shadows && !ctx->lights.empty() && !spheres) ? ctx->tuning.frame_streams : 1;
+		const int lane = (int)(ctx->frame_seq % lanes);
+		if (lane != 0) {
+			// whatever the caller has queued on the context's stream (the G-buffer's producer, an upload's event) comes first
+			const FrameLane ln = rt_frame_lane(ctx, lane);
+			if (ln.stream != ctx->stream) {
+				if (!ctx->ev_order) RT_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+				RT_HIP_CHECK(hipEventRecord(ctx->ev_order, ctx->stream));
+				RT_HIP_CHECK(hipStreamWaitEvent(ln.stream, ctx->ev_order, 0));
+			}
+		}
+		RT_CHECK(frame_async_enqueue(ctx, fs, w, h, tile, rank, nranks, pf, &declined, lane));
+	}
 	if (declined) {
 		// photon-mapped frames, more than 30 lights, frames too large to size by bounds: rendered here and now
 		if (ctx->pending_count > 0) { rt_set_error("this frame needs the synchronous driver: finish the enqueued frame first"); return RT_HIP_ERR_STATE; }
-		RT_CHECK(render_frame_sync(ctx, d_pos_rgb, d_nrm_rgba, fs.uv[0], w, h, 64, 0, 1, d_rgba));
+		if (packed) { rt_set_error("a packed frame that needs the synchronous driver cannot be enqueued"); return RT_HIP_ERR_STATE; }
+		RT_CHECK(render_frame_sync(ctx, d_pos_rgb, d_nrm_rgba, fs.uv[0], w, h, tile, rank, nranks, d_rgba));
 		pf->complete = true;
 		pf->rays = ctx->last_frame_rays;
+		pf->stream = ctx->stream;
 	}
 	pf->used = true;
 	++ctx->pending_count;
+	++ctx->frame_seq;
 	return RT_HIP_OK;
 }
 
@@ -2277,7 +2340,7 @@ int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
 	if (out_rays) *out_rays = pf->rays;
 	ctx->last_frame_rays = pf->rays;
 	pf->used = false;
-	ctx->pending_head ^= 1;
+	ctx->pending_head = (ctx->pending_head + 1) % RT_MAX_PENDING;
 	--ctx->pending_count;
 	return RT_HIP_OK;
 }

@@ -935,7 +935,8 @@ int rt_build_lbvh(rt_hip_ctx* ctx)
 int rt_reserve_spill(rt_hip_ctx* ctx)
 {
 	const int over = ctx->bvh_depth + 2 - ctx->tuning.lds_stack_depth;  // = SceneView::stack_depth - lds depth
-	if (ctx->use_bvh && over > 0) RT_CHECK(ctx->d_spill.reserve((size_t)over * ctx->max_trace_threads * sizeof(int)));
+	// (one set of columns per lane of the frame pipeline: frames of different lanes trace at the same time)
+	if (ctx->use_bvh && over > 0) RT_CHECK(ctx->d_spill.reserve((size_t)over * ctx->max_trace_threads * sizeof(int) * (size_t)std::max(1, ctx->tuning.frame_streams)));
 	return RT_HIP_OK;
 }
 

@@ -99,6 +99,7 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->shadow_prefix = env_int("RT_HIP_SHADOW_PREFIX", 12);
 	t->shadow_prefix_steps = env_int("RT_HIP_SHADOW_PREFIX_STEPS", 24);
 	t->shadow_prefix_min_rays = env_int("RT_HIP_SHADOW_PREFIX_MIN_RAYS", -1);
+	t->frame_streams = env_int("RT_HIP_FRAME_STREAMS", 1);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
@@ -123,6 +124,7 @@ void rt_clamp_tuning(rt_hip_ctx* ctx)
 	t.max_bvh_depth = std::min(95, std::max(1, t.max_bvh_depth));
 	t.shadow_prefix = std::min(30, std::max(0, t.shadow_prefix));
 	t.shadow_prefix_steps = std::min(1024, std::max(1, t.shadow_prefix_steps));
+	t.frame_streams = std::min(RT_MAX_PENDING, std::max(1, t.frame_streams));
 	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;
 }
 
@@ -365,8 +367,8 @@ int rt_hip_create(const rt_hip_config* cfg, rt_hip_ctx** out)
 	if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
 	if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
 	if (e == hipSuccess) e = hipHostMalloc(&ctx->h_small, 4096, hipHostMallocDefault);
-	if (e == hipSuccess) e = hipHostMalloc(&ctx->h_pipe, 1024, hipHostMallocDefault);
-	for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+	if (e == hipSuccess) e = hipHostMalloc(&ctx->h_pipe, 512 * RT_MAX_PENDING, hipHostMallocDefault);
+	for (int k = 0; k < RT_MAX_PENDING && e == hipSuccess; ++k) {
 		ctx->pending[k].h_fc = (int*)((char*)ctx->h_pipe + 512 * k);
 		e = hipEventCreate(&ctx->pending[k].ev0);
 		if (e == hipSuccess) e = hipEventCreate(&ctx->pending[k].ev1);
@@ -405,13 +407,20 @@ int rt_hip_destroy(rt_hip_ctx* ctx)
 	if (ctx->h_pipe) (void)hipHostFree(ctx->h_pipe);
 	if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
 	if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
-	for (int k = 0; k < 2; ++k) {
+	for (int k = 0; k < RT_MAX_PENDING; ++k) {
+		if (ctx->lane_stream[k]) { (void)hipStreamSynchronize(ctx->lane_stream[k]); (void)hipStreamDestroy(ctx->lane_stream[k]); }
+		FrameBufs& fb = ctx->lane_bufs[k];
+		for (DevBuf* b : {&fb.nodes_a, &fb.nodes_b, &fb.gate, &fb.node_inc, &fb.node_uv, &fb.rays_q, &fb.ray_parent, &fb.records, &fb.hits, &fb.occ,
+		                  &fb.child_slot, &fb.fcount, &fb.group_boxes, &fb.prefix, &ctx->d_mg_send_slot[k], &ctx->d_mg_recv_slot[k]})
+			b->release();
 		if (ctx->pending[k].ev0) (void)hipEventDestroy(ctx->pending[k].ev0);
 		if (ctx->pending[k].ev1) (void)hipEventDestroy(ctx->pending[k].ev1);
 		for (hipEvent_t e : {ctx->pending[k].ev_up, ctx->pending[k].ev_done, ctx->pending[k].ev_down})
 			if (e) (void)hipEventDestroy(e);
 		ctx->d_pipe_pos[k].release(); ctx->d_pipe_nrm[k].release(); ctx->d_pipe_img[k].release(); ctx->d_pipe_g16[k].release();
 	}
+	if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
+	if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -892,6 +901,20 @@ int rt_hip_render_tiles_packed_device(rt_hip_ctx* ctx, const float* const* d_gbu
 	return rt_render_frames(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, nframes, width, height, tile, rank, nranks, d_packed_out, 1);
 }
 
+// One frame's packed share, queued without waiting (the frame pipeline's form of rt_hip_render_tiles_packed_device for a host
+// that runs its own exchange); rt_hip_frame_finish completes the oldest enqueued frame.
+int rt_hip_tiles_packed_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width, int height,
+                                       int tile, int rank, int nranks, uint8_t* d_packed_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_packed_out || tile <= 0 || tile % 8 != 0 || nranks <= 1 ||
+	    nranks > RT_MAX_BATCH || rank < 0 || rank >= nranks) {
+		rt_set_error("bad arguments (packed output needs 1 < nranks <= 16 and tile %% 8 == 0)");
+		return RT_HIP_ERR_ARG;
+	}
+	return rt_frame_enqueue(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, d_packed_out, tile, rank, nranks, 1);
+}
+
 int rt_hip_unpack_chunks_device(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int width, int height, int tile,
                                 int nranks, uint8_t* d_frame_rgba)
 {
@@ -942,8 +965,8 @@ int rt_hip_frame_enqueue(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float
 {
 	RT_CHECK(check_ready(ctx));
 	if (width <= 0 || height <= 0 || !gbuf_pos_rgb || !gbuf_nrm_rgba || !rgba_out) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
-	if (ctx->pending_count >= 2) { rt_set_error("two frames are already enqueued: rt_hip_frame_finish() one first"); return RT_HIP_ERR_STATE; }
-	const int slot = (ctx->pending_head + ctx->pending_count) & 1;
+	int slot = 0;
+	RT_CHECK(rt_pipeline_slot(ctx, &slot));
 	PendingFrame* pf = &ctx->pending[slot];
 	if (!ctx->up_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
 	if (!ctx->down_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
@@ -961,7 +984,7 @@ int rt_hip_frame_enqueue(rt_hip_ctx* ctx, const float* gbuf_pos_rgb, const float
 	RT_HIP_CHECK(hipStreamWaitEvent(ctx->stream, pf->ev_up, 0));
 	RT_CHECK(rt_frame_enqueue(ctx, ctx->d_pipe_pos[slot].as<float>(), ctx->d_pipe_nrm[slot].as<float>(), width, height,
 	                          ctx->d_pipe_img[slot].as<uint8_t>()));
-	RT_HIP_CHECK(hipEventRecord(pf->ev_done, ctx->stream));
+	RT_HIP_CHECK(hipEventRecord(pf->ev_done, pf->stream));  // (the stream of the lane the frame was dealt to)
 	RT_HIP_CHECK(hipStreamWaitEvent(ctx->down_stream, pf->ev_done, 0));
 	RT_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_pipe_img[slot].p, npix * 4, hipMemcpyDeviceToHost, ctx->down_stream));
 	RT_HIP_CHECK(hipEventRecord(pf->ev_down, ctx->down_stream));
@@ -979,8 +1002,8 @@ int rt_hip_frame_enqueue_g16(rt_hip_ctx* ctx, const uint16_t* gbuf_nrm_rgba16, c
 {
 	RT_CHECK(check_ready(ctx));
 	if (width <= 0 || height <= 0 || !gbuf_nrm_rgba16 || !gbuf_pos_rgb16f || !rgba_out) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
-	if (ctx->pending_count >= 2) { rt_set_error("two frames are already enqueued: rt_hip_frame_finish() one first"); return RT_HIP_ERR_STATE; }
-	const int slot = (ctx->pending_head + ctx->pending_count) & 1;
+	int slot = 0;
+	RT_CHECK(rt_pipeline_slot(ctx, &slot));
 	PendingFrame* pf = &ctx->pending[slot];
 	if (!ctx->up_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
 	if (!ctx->down_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
@@ -1001,7 +1024,7 @@ int rt_hip_frame_enqueue_g16(rt_hip_ctx* ctx, const uint16_t* gbuf_nrm_rgba16, c
 	RT_CHECK(rt_launch_decode_g16(ctx, d_n16, d_p16, (int)npix, ctx->d_pipe_nrm[slot].as<float>(), ctx->d_pipe_pos[slot].as<float>()));
 	RT_CHECK(rt_frame_enqueue(ctx, ctx->d_pipe_pos[slot].as<float>(), ctx->d_pipe_nrm[slot].as<float>(), width, height,
 	                          ctx->d_pipe_img[slot].as<uint8_t>()));
-	RT_HIP_CHECK(hipEventRecord(pf->ev_done, ctx->stream));
+	RT_HIP_CHECK(hipEventRecord(pf->ev_done, pf->stream));  // (the stream of the lane the frame was dealt to)
 	RT_HIP_CHECK(hipStreamWaitEvent(ctx->down_stream, pf->ev_done, 0));
 	RT_HIP_CHECK(hipMemcpyAsync(rgba_out, ctx->d_pipe_img[slot].p, npix * 4, hipMemcpyDeviceToHost, ctx->down_stream));
 	RT_HIP_CHECK(hipEventRecord(pf->ev_down, ctx->down_stream));
@@ -1015,18 +1038,19 @@ int rt_hip_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
 {
 	RT_CHECK(check_ctx(ctx));
 	PendingFrame* pf = ctx->pending_count > 0 ? &ctx->pending[ctx->pending_head] : nullptr;
-	const bool host = pf && pf->host;
+	const bool comm = pf && pf->comm;                 // rt_hip_frame_multi_enqueue_device: ev_down = the assembled image is in place
+	const bool host = pf && (pf->host || comm);
 	hipEvent_t ev_down = host ? pf->ev_down : nullptr;
 	uint8_t* h_rgba = host ? pf->h_rgba : nullptr;
 	const uint8_t* d_img = host ? pf->fs.rgba[0] : nullptr;
 	const size_t bytes = host ? pf->img_bytes : 0;
-	if (pf) pf->host = false;
+	if (pf) { pf->host = false; pf->comm = false; }
 	const int status = rt_frame_finish(ctx, out_rays);
 	if (host) {
 		// also when the finish failed: the caller's buffer must not be written to after this call has returned
 		RT_HIP_CHECK(hipEventSynchronize(ev_down));
 		RT_CHECK(status);
-		if (ctx->frame_redone) {
+		if (ctx->frame_redone && !comm) {
 			// the frame was rendered again after the download had been queued (a level overflowed its bound): fetch it again
 			RT_HIP_CHECK(hipMemcpyAsync(h_rgba, d_img, bytes, hipMemcpyDeviceToHost, ctx->stream));
 			RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1303,6 +1327,11 @@ int rt_hip_sync(rt_hip_ctx* ctx)
 {
 	RT_CHECK(check_ctx(ctx));
 	RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	// and the streams of the frame pipeline's other lanes, of its copies and of its collectives
+	for (int k = 1; k < RT_MAX_PENDING; ++k)
+		if (ctx->lane_stream[k]) RT_HIP_CHECK(hipStreamSynchronize(ctx->lane_stream[k]));
+	for (hipStream_t st : {ctx->up_stream, ctx->down_stream, ctx->comm_stream})
+		if (st) RT_HIP_CHECK(hipStreamSynchronize(st));
 	return RT_HIP_OK;
 }
 

@@ -104,6 +104,23 @@ struct FrameSet {
 	int packed;            // 1: rgba[f] is the PACKED chunk of the rank's tiles (tile after tile, row-major inside), not a frame
 };
 
+// The frame pipeline: at most RT_MAX_PENDING frames enqueued and not finished, dealt to tuning.frame_streams lanes.  A lane =
+// a HIP stream + the level arrays of one frame (lane 0: the context's stream and the context's own arrays, which the
+// synchronous driver uses too).  Frames of one lane run in order; frames of different lanes side by side.
+// Four: the box runs four hardware queues per process (GPU_MAX_HW_QUEUES), and a fourth lane already shares one with the others:
+// an eighth of the 1080p frame took 0.310 / 0.200 / 0.157 / 0.184 ms per frame with 1 / 2 / 3 / 4 lanes (scripts/share_lanes_probe.py).
+constexpr int RT_MAX_PENDING = 4;
+struct FrameBufs {
+	DevBuf nodes_a, nodes_b, gate, node_inc, node_uv, rays_q, ray_parent, records, hits, occ, child_slot, fcount, group_boxes, prefix;
+};
+struct FrameLane {  // what frame_async_enqueue works on
+	hipStream_t stream;
+	DevBuf *nodes_a, *nodes_b, *gate, *node_inc, *node_uv, *rays_q, *ray_parent, *records, *hits, *occ, *child_slot, *fcount, *group_boxes, *prefix;
+	const int** fcount_clean;  // the lane's d_fcount[0, *fcount_clean_n) is known to be zero
+	int* fcount_clean_n;
+	int index;
+};
+
 // A frame whose kernels are queued and whose counters the host has not read yet (sync-free frame driver).
 struct PendingFrame {
 	bool used = false;
@@ -114,6 +131,8 @@ struct PendingFrame {
 	int n0 = 0, bounces = 0, nframes = 0, num_lights = 0;
 	bool shadows = false;
 	bool can_overflow = false;   // some level's bound is the level cap: the frame may have to be redone with host-sized levels
+	hipStream_t stream = nullptr; // the lane's stream the frame was queued on
+	bool comm = false;            // rt_hip_frame_multi_enqueue_device: ev_down = all-gather and unpack done (on the communicator's stream)
 	int64_t rays = 0;
 	// what a repeat on the synchronous driver needs (a level overflowed its bound)
 	FrameSet fs;
@@ -134,13 +153,21 @@ struct rt_hip_ctx {
 	std::vector<int> trace_event_class;                           // 0 closest, 1 any
 	size_t trace_events_used = 0;
 	size_t trace_events_collected = 0;                            // [collected, used) are still to be folded into the stats
-	PendingFrame pending[2];                                      // the frame pipeline (rt_hip_frame_enqueue_device / _finish)
+	PendingFrame pending[RT_MAX_PENDING];                         // the frame pipeline (rt_hip_frame_enqueue_device / _finish): a ring
 	int pending_head = 0, pending_count = 0;                      // oldest slot, frames enqueued and not finished
 	bool frame_redone = false;                                    // the last rt_frame_finish rendered its frame again (level overflow)
-	void* h_pipe = nullptr;                                       // pinned: 2 x 512 B of frame counters
+	void* h_pipe = nullptr;                                       // pinned: RT_MAX_PENDING x 512 B of frame counters
+	int64_t frame_seq = 0;                                        // frames enqueued so far: frame j runs on lane j % lanes
+	hipStream_t lane_stream[RT_MAX_PENDING] = {};                 // streams of lanes 1 ..; created on first use
+	FrameBufs lane_bufs[RT_MAX_PENDING];                          // level arrays of lanes 1 .. (lane 0: the d_* members below)
+	const int* lane_fcount_clean[RT_MAX_PENDING] = {};
+	int lane_fcount_clean_n[RT_MAX_PENDING] = {};
+	hipEvent_t ev_order = nullptr;                                // orders a lane's stream behind the context's stream at enqueue
+	hipStream_t comm_stream = nullptr;                            // rt_hip_frame_multi_enqueue_device: all-gathers and unpacks, in frame order
+	DevBuf d_mg_send_slot[RT_MAX_PENDING], d_mg_recv_slot[RT_MAX_PENDING];
 	hipStream_t up_stream = nullptr, down_stream = nullptr;       // rt_hip_frame_enqueue: G-buffer up / image down beside the frame's stream
-	DevBuf d_pipe_pos[2], d_pipe_nrm[2], d_pipe_img[2];           // its device staging, one set per pending slot
-	DevBuf d_pipe_g16[2];                                         // rt_hip_frame_enqueue_g16: the 14 B / texel planes as they crossed PCIe
+	DevBuf d_pipe_pos[RT_MAX_PENDING], d_pipe_nrm[RT_MAX_PENDING], d_pipe_img[RT_MAX_PENDING];  // its device staging, one set per pending slot
+	DevBuf d_pipe_g16[RT_MAX_PENDING];                                         // rt_hip_frame_enqueue_g16: the 14 B / texel planes as they crossed PCIe
 	DevBuf d_census, d_spill, d_tile_list;
 	int tile_key[5] = {0, 0, 0, 0, 0};                            // (w, h, tile, rank, nranks) of d_tile_list
 	int tile_count = 0;
@@ -273,13 +300,16 @@ int rt_launch_tiles_pack(rt_hip_ctx* ctx, bool pack, uint8_t* d_frame, int w, in
 int rt_render_gbuffer(rt_hip_ctx* ctx, float fov, int w, int h, float* d_nrm_rgba, float* d_pos_rgb, float* d_uv = nullptr);
 int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, int tile,
                     int rank, int nranks, uint8_t* d_rgba);
-int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba);
+int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba,
+                     int tile = 64, int rank = 0, int nranks = 1, int packed = 0);
+int rt_pipeline_slot(rt_hip_ctx* ctx, int* slot);  // the ring slot the next enqueued frame takes, or RT_HIP_ERR_STATE when the pipeline is full
+FrameLane rt_frame_lane(rt_hip_ctx* ctx, int lane);
 int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays);
 int rt_launch_decode_g16(rt_hip_ctx* ctx, const uint16_t* d_nrm16, const uint16_t* d_pos16, int n, float* d_nrm_rgba, float* d_pos_rgb);
 int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
                      int h, int tile, int rank, int nranks, uint8_t* const* d_rgba, int packed = 0);
 int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int w, int h, int tile, int nranks,
-                     uint8_t* d_frame);
+                     uint8_t* d_frame, hipStream_t st = nullptr);  // nullptr: ctx->stream
 
 // ---- k_noalloc.hip -------------------------------------------------------------------------------
 int rt_noalloc_setup(int device);  // once per device, that device current

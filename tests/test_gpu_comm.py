@@ -34,6 +34,31 @@ def test_one_rank_communicator_reproduces_single_gpu_results():
         g.render_frame_multi_device(d_p, d_n, w, h, tile, out)
         assert torch.equal(out, whole), "tile %d" % tile
         assert g.last_frame_rays() == rays
+    # the pipelined form: frames queued without waiting, on one and on three lanes, finished in order
+    gbs, wholes = [(d_p, d_n)], [(whole, rays)]
+    for f in (1, 2, 3):
+        n2 = torch.zeros_like(d_n); p2 = torch.zeros_like(d_p)
+        g.render_gbuffer_device(sc.fov - 0.05 * f, w, h, n2, p2)
+        o2 = torch.zeros_like(whole)
+        g.render_frame_device(p2, n2, w, h, o2)
+        gbs.append((p2, n2)); wholes.append((o2, g.last_frame_rays()))
+    enqueue = rt.RtHip.frame_multi_enqueue_device.__wrapped__ if hasattr(rt.RtHip.frame_multi_enqueue_device, "__wrapped__") else rt.RtHip.frame_multi_enqueue_device
+    for streams in (1, 3):
+        g.set_tuning(frame_streams=streams)
+        outs = [torch.full((w * h * 4,), 7, dtype=torch.uint8, device="cuda") for _ in range(8)]
+        torch.cuda.synchronize()
+        got, pending = [], 0
+        for k in range(8):
+            if pending == max(2, streams):
+                got.append(g.frame_finish()); pending -= 1
+            enqueue(g, gbs[k % 4][0], gbs[k % 4][1], w, h, 64, outs[k]); pending += 1
+        while pending:
+            got.append(g.frame_finish()); pending -= 1
+        g.sync()
+        for k in range(8):
+            assert torch.equal(outs[k], wholes[k % 4][0]), "streams %d, frame %d" % (streams, k)
+            assert got[k] == wholes[k % 4][1]
+    g.set_tuning(frame_streams=1)
     again = torch.zeros_like(whole)
     g.render_frame_device(d_p, d_n, w, h, again)       # the single-GPU entry is undisturbed
     assert torch.equal(again, whole)

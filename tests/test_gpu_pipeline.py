@@ -144,3 +144,64 @@ def test_g16_pipeline_is_bit_identical_to_the_float_entry():
         assert np.array_equal(outs[k].numpy(), frames[k][2]), "frame %d" % k
     assert int(outs[0].numpy().reshape(-1, 4)[:, :3].max()) > 40
     g.close()
+
+
+@pytest.mark.parametrize("streams", [2, 3, 4])
+def test_frames_on_several_streams_equal_sequential_frames(streams):
+    """tuning.frame_streams > 1: enqueued frames are dealt to that many lanes (a stream and level arrays each) and run side by
+    side.  Images and ray counts must be the sequential ones, in order, for device frames, for frames from host buffers
+    (float and 16-bit G-buffer), also with a shallow LDS stack (every lane needs its own overflow columns in HBM) and with
+    the shadow rays' shared descent forced on."""
+    import torch
+    import raytracer_amd as rt
+    sc = scenes.atrium(8192)
+    g = rt.RtHip(sc, semantics="array", accel=rt.ACCEL_PLOC, bounces=2, do_shadows=1, shadow_t_max=1.0, profile=1,
+                 tuning=dict(lds_stack_depth=3, shadow_prefix_min_rays=0))
+    w, h = 320, 200
+    nf = 7
+    gb, exp, host = [], [], []
+    for f in range(nf):
+        d_n = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+        d_p = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+        g.render_gbuffer_device(sc.fov - 0.04 * f, w, h, d_n, d_p)
+        out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+        g.render_frame_device(d_p, d_n, w, h, out)
+        gb.append((d_p, d_n))
+        exp.append((out.cpu().numpy(), g.last_frame_rays()))
+        host.append((d_p.cpu().pin_memory(), d_n.cpu().pin_memory()))
+    assert len({r for _, r in exp}) > 1
+    g.set_tuning(frame_streams=streams)
+    assert g.tuning()["frame_streams"] == streams
+    enqueue = rt.RtHip.frame_enqueue_device.__wrapped__
+    outs = [torch.full((w * h * 4,), 3, dtype=torch.uint8, device="cuda") for _ in range(nf)]
+    torch.cuda.synchronize()
+    got, pending = [], 0
+    for f in range(nf):
+        if pending == max(2, streams):
+            with pytest.raises(rt.RtHipError, match="already enqueued"):
+                enqueue(g, gb[f][0], gb[f][1], w, h, outs[f])
+            got.append(g.frame_finish()); pending -= 1
+        enqueue(g, gb[f][0], gb[f][1], w, h, outs[f]); pending += 1
+    while pending:
+        got.append(g.frame_finish()); pending -= 1
+    g.sync()
+    assert got == [r for _, r in exp]
+    for f in range(nf):
+        assert np.array_equal(outs[f].cpu().numpy(), exp[f][0]), "image of frame %d" % f
+    # host buffers: uploads, frames on their lanes, downloads
+    h_outs = [torch.full((w * h * 4,), 5, dtype=torch.uint8).pin_memory() for _ in range(nf)]
+    got, pending = [], 0
+    for f in range(nf):
+        if pending == max(2, streams):
+            got.append(g.frame_finish()); pending -= 1
+        g.frame_enqueue_host(host[f][0], host[f][1], w, h, h_outs[f]); pending += 1
+    while pending:
+        got.append(g.frame_finish()); pending -= 1
+    assert got == [r for _, r in exp]
+    for f in range(nf):
+        assert np.array_equal(h_outs[f].numpy(), exp[f][0]), "host image of frame %d" % f
+    # the other entries still work between pipelines and see the same scene
+    again = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    g.render_frame_device(gb[2][0], gb[2][1], w, h, again)
+    assert np.array_equal(again.cpu().numpy(), exp[2][0])
+    g.close()
