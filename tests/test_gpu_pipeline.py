@@ -205,3 +205,40 @@ def test_frames_on_several_streams_equal_sequential_frames(streams):
     g.render_frame_device(gb[2][0], gb[2][1], w, h, again)
     assert np.array_equal(again.cpu().numpy(), exp[2][0])
     g.close()
+
+
+def test_packed_shares_through_the_pipeline_equal_the_blocking_entry():
+    """rt_hip_tiles_packed_enqueue_device: every virtual rank's packed share of a frame, three frames in flight on three
+    lanes, equals what rt_hip_render_tiles_packed_device writes; unpacked, the chunks are the whole frame."""
+    import torch
+    import raytracer_amd as rt
+    from raytracer_amd.tiles import max_owned_tiles
+    sc = scenes.atrium(8192)
+    g = rt.RtHip(sc, semantics="array", accel=rt.ACCEL_PLOC, bounces=2, do_shadows=1, shadow_t_max=1.0)
+    w, h, tile, nranks = 320, 200, 16, 3
+    d_n = torch.zeros(w * h * 4, dtype=torch.float32, device="cuda")
+    d_p = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    g.render_gbuffer_device(sc.fov, w, h, d_n, d_p)
+    whole = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    g.render_frame_device(d_p, d_n, w, h, whole)
+    chunk = max_owned_tiles(w, h, tile, nranks) * tile * tile * 4
+    ref = torch.zeros(nranks * chunk, dtype=torch.uint8, device="cuda")
+    rays = []
+    for r in range(nranks):
+        g.render_tiles_packed_device([d_p], [d_n], w, h, tile, r, nranks, [ref[r * chunk:(r + 1) * chunk]])
+        rays.append(g.last_frame_rays())
+    g.set_tuning(frame_streams=3)
+    enq = rt.RtHip.tiles_packed_enqueue_device.__wrapped__
+    got = torch.zeros(nranks * chunk, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(nranks):                                   # the three ranks' shares side by side
+        enq(g, d_p, d_n, w, h, tile, r, nranks, got[r * chunk:(r + 1) * chunk])
+    assert [g.frame_finish() for _ in range(nranks)] == rays
+    g.sync()
+    assert torch.equal(got, ref)
+    out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    g.unpack_chunks_device(got, chunk, w, h, tile, nranks, out)
+    assert torch.equal(out, whole)
+    with pytest.raises(rt.RtHipError):
+        enq(g, d_p, d_n, w, h, tile, 0, 1, got[:chunk])       # one rank: nothing to pack
+    g.close()
