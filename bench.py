@@ -215,14 +215,16 @@ def main():
         g.update()
     build_stats = g.stats()
     photon_info = None
-    strong_cabi_early = args.scaling == "strong" and world > 1 and args.route == "cabi" and backend == "nccl"
+    # BENCH_REHEARSE_CABI=1: the N > 1 route (communicator, rt_hip_frame_multi_enqueue_device, verification) with ONE rank, on a one-GPU box
+    rehearse = world == 1 and os.environ.get("BENCH_REHEARSE_CABI") == "1"
+    strong_cabi_early = args.scaling == "strong" and (world > 1 or rehearse) and args.route == "cabi" and backend == "nccl"
     if strong_cabi_early:
         # one communicator per context, created by the library (ncclCommInitRank); only the 128-byte id travels through torch
         def bcast(mine):
             box = [mine]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        g.comm_init(rank, world, broadcast=bcast)
+        g.comm_init(rank, world, broadcast=bcast if world > 1 else None)
     if args.photons > 0:
         from raytracer_amd.photons import build_photon_map
         torch.cuda.synchronize(dev)
@@ -237,7 +239,7 @@ def main():
 
     strong = args.scaling == "strong"          # at N = 1 a label only: one frame per sub-step either way
     # the library's own RCCL route needs one GPU per rank; the gloo rehearsal (all ranks on device 0) takes the torch route
-    cabi = strong and world > 1 and args.route == "cabi" and backend == "nccl"
+    cabi = strong and (world > 1 or rehearse) and args.route == "cabi" and backend == "nccl"
     K = args.frames_per_step if args.frames_per_step > 0 else (2 if args.photons > 0 else 300)
     # frames in flight inside ONE context (tuning.frame_streams): the tail of one frame's launches is filled by the next frame's waves
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (3 if cabi and args.photons == 0 else 1)
@@ -334,7 +336,7 @@ def main():
     # N = 1: frames go through the library's pipeline (rt_hip_frame_enqueue_device / rt_hip_frame_finish): frame k + 1 is
     # queued before frame k's counters are read back, so the host's per-frame work runs under the GPU's.  Every frame is
     # still rendered whole and in order; BENCH_PIPELINE=0 takes the call-per-frame entry instead.
-    pipelined = world == 1 and args.photons == 0 and os.environ.get("BENCH_PIPELINE", "1") != "0"
+    pipelined = world == 1 and not cabi and args.photons == 0 and os.environ.get("BENCH_PIPELINE", "1") != "0"
     enqueue = rt.RtHip.frame_enqueue_device.__wrapped__
 
     def run_steps(count):
@@ -421,12 +423,13 @@ def main():
         whole = torch.zeros(npix * 4, dtype=torch.uint8, device=dev)
         g.render_frame_device(gb_p[0 if strong else rank], gb_n[0 if strong else rank], W, H, whole)
         ok = torch.tensor([1.0 if torch.equal(whole, frame) else 0.0], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         tiles_verified = bool(ok.item() == 1.0)
 
     # ---- untimed extras on rank 0 at N = 1: the spans SURVEY 8d defines around the device-resident frame ----
     extras, target, more = {}, None, {}
-    if rank == 0 and world == 1 and not args.no_extras and args.photons == 0 and inflight == 1 and fif == 1:
+    if rank == 0 and world == 1 and not args.no_extras and args.photons == 0 and inflight == 1 and fif == 1 and not cabi:
         extras, target = run_extras(args, rt, scenes, g, scene, gb_p[0], gb_n[0], W, H, dev, dev_index, ACCEL)
         more = run_more_configs(args, rt, scenes, g, scene, gb_p[0], gb_n[0], W, H, dev, dev_index, ACCEL, elapsed / frames_done * 1e3)
 
