@@ -718,8 +718,29 @@ def run_extras(args, rt, scenes, g, scene, gb_p, gb_n, W, H, dev, dev_index, ACC
         cfg["ms_per_frame_host_to_host_g16_pipelined"] = round((time.perf_counter() - t0) * 1e3 / n, 3)
         cfg["host_to_host_g16_note"] = ("rt_hip_frame_enqueue_g16: RGBA16 UNORM normals + RGB16F positions (the rasterizer's FBO formats, ras_rasterizer.cpp:293,301), "
                                         "%.1f MB up per frame, widened on the device; image identical to the float entry's: %s" % (npix * 14 / 1e6, same))
+        # ... and with three frames in flight (tuning.frame_streams = 3): uploads, frames on three streams, downloads
+        g.set_tuning(frame_streams=3)
+        outs3 = (h_o, h_o2, torch.zeros(npix * 4, dtype=torch.uint8).pin_memory())
+        for k in range(3):
+            g.frame_enqueue_host_g16(h_n16, h_p16, W, H, outs3[k])
+        for k in range(3):
+            g.frame_finish()
+        n, pend = 60, 0
+        t0 = time.perf_counter()
+        for i in range(n):
+            if pend == 3:
+                g.frame_finish(); pend -= 1
+            g.frame_enqueue_host_g16(h_n16, h_p16, W, H, outs3[i % 3]); pend += 1
+        while pend:
+            g.frame_finish(); pend -= 1
+        cfg["ms_per_frame_host_to_host_g16_3_in_flight"] = round((time.perf_counter() - t0) * 1e3 / n, 3)
+        same3 = bool(torch.equal(ref_img, outs3[2]))
+        cfg["host_to_host_g16_3_in_flight_note"] = ("the same entry with tuning.frame_streams = 3, %d frames; image identical: %s (no gain expected here: two copy streams "
+                                                    "and three lanes share the process's four hardware queues, and the upload is the longer leg)" % (n, same3))
+        g.set_tuning(frame_streams=1)
         del h_n16, h_p16
     except Exception as e:
+        g.set_tuning(frame_streams=1)
         cfg["host_to_host_g16_note"] = "not measured: %r" % (e,)
     # one frame at a time, as SURVEY 8d words the GPU timing (3 warm-up + 20 timed, median and p95): call -> image complete,
     # host clock around rt_hip_render_frame_device + stream sync, G-buffer and image resident in HBM
