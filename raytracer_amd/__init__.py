@@ -482,7 +482,7 @@ class RtHip:
         self._ck(self.lib.rt_hip_frame_enqueue_g16(self.h, ptr(h_nrm_rgba16), ptr(h_pos_rgb16f), w, h, ptr(h_rgba)))
 
     def frame_enqueue_device(self, d_pos_rgb, d_nrm_rgba, w, h, d_rgba):
-        """Queue a whole frame without waiting for it (at most two unfinished); frame_finish() completes the oldest."""
+        """Queue a whole frame without waiting for it (at most max(2, tuning.frame_streams) unfinished); frame_finish() completes the oldest."""
         self._ck(self.lib.rt_hip_frame_enqueue_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, _dptr(d_rgba)))
 
     def frame_finish(self):
