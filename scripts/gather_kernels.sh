@@ -10,8 +10,8 @@ import csv, sys
 out = []
 for r in csv.DictReader(open("gpurun_out/gk_prof/gk_kernel_stats.csv")):
     n = r["Name"]
-    if "photon_gather" in n or "photon_classify" in n or "photon_select" in n:
-        tag = ("classify" if "classify" in n else "select_common" if "select_common" in n else "wave<1>" if "wave<true, 1>" in n else "wave<2>" if "wave<true, 2>" in n
+    if "photon_gather" in n or "photon_classify" in n or "photon_select" in n or "photon_pass1_group" in n:
+        tag = ("group" if "pass1_group" in n else "classify" if "classify" in n else "select_common" if "select_common" in n else "wave<1>" if "wave<true, 1>" in n else "wave<2>" if "wave<true, 2>" in n
                else "wave<0>" if "gather_wave" in n else "lane")
         out.append("%s %.3f ms" % (tag, float(r["AverageNs"]) / 1e6))
 import os

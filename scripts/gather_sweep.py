@@ -15,8 +15,13 @@ n = build_photon_map(g, per_light, len(sc.lights), "cuda")
 d_n = torch.zeros(W * H * 4, dtype=torch.float32, device="cuda")
 d_p = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
 g.render_gbuffer_device(sc.fov, W, H, d_n, d_p); g.sync()
-nr = d_n.view(-1, 4); cov = nr[:, 3] > 0
-pos = d_p.view(-1, 3)[cov].contiguous(); nrm = (nr[cov, :3] * 2 - 1).contiguous()
+nr = d_n.view(-1, 4)
+pp = d_p.view(-1, 3)
+if os.environ.get("SWEEP_TILE_ORDER", "1") != "0":   # 8 x 8 tiles, the order of the frame's level-0 points
+    idx = torch.arange(W * H, device="cuda").view(H // 8, 8, W // 8, 8).permute(0, 2, 1, 3).reshape(-1)
+    nr, pp = nr[idx], pp[idx]
+cov = nr[:, 3] > 0
+pos = pp[cov].contiguous(); nrm = (nr[cov, :3] * 2 - 1).contiguous()
 out = torch.zeros_like(pos)
 base = g.tuning()
 for spec in sys.argv[2:]:
