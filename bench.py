@@ -122,6 +122,9 @@ def parse_args():
                     help="frames the library's pipeline keeps in flight on streams of their own (tuning.frame_streams, 1..4). 0 = auto: 1 at N = 1 "
                          "(launches that do not overlap, which is what the roofline object prices), 3 for a frame split over N > 1 GPUs "
                          "through the C ABI (rt_hip_frame_multi_enqueue_device)")
+    ap.add_argument("--frames-per-entry", type=int, default=0,
+                    help="N > 1 through the C ABI: frames per pipeline entry (rt_hip_frames_multi_enqueue_device: one pass of launches and one "
+                         "all-gather for all of them, 1..8). 0 = auto: N / 2, at most 4 -- every launch then as large as half a frame's")
     ap.add_argument("--tuning", default="", help="rt_hip_tuning overrides, name=value,name=value (variant measurements; results never depend on them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -246,6 +249,10 @@ def main():
     fif = max(1, min(4, fif)) if args.photons == 0 else 1
     if fif > 1:
         g.set_tuning(frame_streams=fif)
+    # frames per pipeline entry (rt_hip_frames_multi_enqueue_device): with the frame split N ways, N / 2 frames per entry keep
+    # every launch as large as half a frame's and every all-gather as large as half a frame
+    fpe = args.frames_per_entry if args.frames_per_entry > 0 else (max(1, min(4, world // 2)) if cabi and args.photons == 0 else 1)
+    fpe = max(1, min(8, fpe)) if (cabi and args.photons == 0) else 1
 
     # ---- inputs resident in HBM: one G-buffer per frame of a sub-step -------------------------
     nframes = 1 if (strong or world == 1) else world
@@ -272,8 +279,9 @@ def main():
     render_batch = rt.RtHip.render_tiles_batch_device.__wrapped__
     render_multi = rt.RtHip.render_frame_multi_device.__wrapped__
     enqueue_multi = rt.RtHip.frame_multi_enqueue_device.__wrapped__
-    outs_fif = [tiles[0]] + [torch.zeros(npix * 4, dtype=torch.uint8, device=dev) for _ in range(fif - 1)]   # one image per frame in flight
-    if cabi and fif > 1:
+    enqueue_multi_batch = rt.RtHip.frames_multi_enqueue_device.__wrapped__
+    outs_fif = [tiles[0]] + [torch.zeros(npix * 4, dtype=torch.uint8, device=dev) for _ in range(fif * fpe - 1)]   # one image per frame in flight
+    if cabi and (fif > 1 or fpe > 1):
         frame = outs_fif[0]
 
     def substep():
@@ -340,14 +348,21 @@ def main():
     enqueue = rt.RtHip.frame_enqueue_device.__wrapped__
 
     def run_steps(count):
-        if cabi and fif > 1:
-            # the split frame through the library's pipeline: up to `fif` frames queued (their shares side by side on this GPU, the
-            # all-gather of one under the kernels of the next), finished oldest first -- every rank in the same order
-            total, rays, pend = count * K, 0, 0
-            for k in range(total):
-                if pend == fif:
+        if cabi and (fif > 1 or fpe > 1):
+            # the split frame through the library's pipeline: up to `fif` entries of `fpe` frames queued (their shares side by side
+            # on this GPU, the all-gather of one under the kernels of the next), finished oldest first -- every rank in the same order
+            total, rays, pend, k = count * K, 0, 0, 0
+            limit = max(2, fif) if fif > 1 else 1
+            while total > 0:
+                nf = min(fpe, total)
+                if pend == limit:
                     rays += g.frame_finish(); pend -= 1
-                enqueue_multi(g, gb_p[0], gb_n[0], W, H, 64, outs_fif[k % fif]); pend += 1
+                o = outs_fif[(k % fif) * fpe:(k % fif) * fpe + nf]
+                if nf == 1:
+                    enqueue_multi(g, gb_p[0], gb_n[0], W, H, 64, o[0])
+                else:
+                    enqueue_multi_batch(g, [gb_p[0]] * nf, [gb_n[0]] * nf, W, H, 64, o)
+                pend += 1; k += 1; total -= nf
             while pend:
                 rays += g.frame_finish(); pend -= 1
             return rays
@@ -406,7 +421,7 @@ def main():
     frames_done = substeps * nframes
 
     lone_latency = None
-    if cabi and fif > 1:
+    if cabi and (fif > 1 or fpe > 1):
         # latency of ONE split frame (nothing else in flight), untimed: 10 calls of the blocking entry
         render_multi(g, gb_p[0], gb_n[0], W, H, 64, frame)
         fence()
@@ -463,6 +478,8 @@ def main():
                        **({"frames_in_flight": inflight} if inflight > 1 else {}),
                        **({"frames_in_flight": fif, "frames_in_flight_note": "tuning.frame_streams: that many frames of the library's pipeline run side by side on "
                            "streams of their own; a k_shadow launch then shares the GPU with another frame's, so avg_launch_ms is not the launch's own cost"} if fif > 1 else {}),
+                       **({"frames_per_entry": fpe, "frames_per_entry_note": "rt_hip_frames_multi_enqueue_device: this rank's tiles of that many frames are shaded by one pass "
+                           "of launches and travel in one all-gather; the frames of an entry are finished together (frame_latency_ms is a lone frame's)"} if fpe > 1 else {}),
                        **({"frame_pipeline": "rt_hip_frame_enqueue_device / rt_hip_frame_finish, one frame queued ahead"} if (pipelined and inflight == 1) else {}),
                        "rays_per_frame": round(total_rays / frames_done, 1),
                        "ms_per_frame": round(ms_per_frame, 4),
@@ -475,7 +492,8 @@ def main():
                        "bvh_build_ms": round(build_stats["build_ms"], 3), "bvh_depth": build_stats["bvh_depth"],
                        **extras,
                        **({"multi_gpu_route": ("C ABI: rt_hip_comm_init (id broadcast over torch.distributed) + " +
-                                               ("rt_hip_frame_multi_enqueue_device / rt_hip_frame_finish, %d frames in flight: " % fif if fif > 1 else "rt_hip_render_frame_multi_device: ") +
+                                               (("rt_hip_frames_multi_enqueue_device / rt_hip_frame_finish, %d entries of %d frames in flight: " % (fif, fpe)) if fpe > 1 else
+                                                ("rt_hip_frame_multi_enqueue_device / rt_hip_frame_finish, %d frames in flight: " % fif) if fif > 1 else "rt_hip_render_frame_multi_device: ") +
                                                "RCCL all-gather of the packed tiles inside the library, every rank holds the whole frame" if cabi else
                                                "torch.distributed: raytracer_amd/frames.py"),
                            "exchange": ("all-gather of packed tiles after every frame" if strong else
@@ -951,6 +969,28 @@ def _strong_share(rt, torch, g, d_p, d_n, w, h, whole_ms, reps=6):
             g.set_tuning(frame_streams=1)
             out[str(n)]["slowest_rank_ms_3_in_flight"] = round(dt, 4)
             out[str(n)]["implied_efficiency_3_in_flight"] = round(whole_ms / (n * (dt + un)), 3)
+            # ... and in entries of N / 2 frames (at most 4), three entries in flight: what bench.py --gpus N queues per rank by default
+            # (rt_hip_frames_multi_enqueue_device minus its all-gather)
+            fpe = max(1, min(4, n // 2))
+            if fpe > 1:
+                enqb = type(g).tiles_packed_batch_enqueue_device.__wrapped__
+                dstb = [[torch.zeros(chunk, dtype=torch.uint8, device=d_p.device) for _ in range(fpe)] for _ in range(3)]
+                g.set_tuning(frame_streams=3)
+                def pipedb(k):
+                    pend = 0
+                    for i in range(k):
+                        if pend == 3:
+                            g.frame_finish(); pend -= 1
+                        enqb(g, [d_p] * fpe, [d_n] * fpe, w, h, 64, r, n, dstb[i % 3]); pend += 1
+                    while pend:
+                        g.frame_finish(); pend -= 1
+                    g.sync()
+                pipedb(6)
+                t0 = time.perf_counter(); pipedb(5 * reps); dtb = (time.perf_counter() - t0) / (5 * reps * fpe) * 1e3
+                g.set_tuning(frame_streams=1)
+                out[str(n)]["frames_per_entry"] = fpe
+                out[str(n)]["slowest_rank_ms_entries_3_in_flight"] = round(dtb, 4)
+                out[str(n)]["implied_efficiency_entries_3_in_flight"] = round(whole_ms / (n * (dtb + un)), 3)
         except Exception as e:
             g.set_tuning(frame_streams=1)
             out[str(n)]["in_flight_error"] = repr(e)

@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "rt_hip_render_gbuffer_uv_device",
     "rt_hip_get_stats", "rt_hip_reset_stats", "rt_hip_sync", "rt_hip_stream", "rt_hip_get_bvh",
     "rt_hip_trace_census_device", "rt_hip_gbuffer_select_noalloc_device",
-    "rt_hip_frame_enqueue_device", "rt_hip_frame_enqueue", "rt_hip_frame_enqueue_g16", "rt_hip_frame_finish", "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device", "rt_hip_frame_multi_enqueue_device", "rt_hip_tiles_packed_enqueue_device",
+    "rt_hip_frame_enqueue_device", "rt_hip_frame_enqueue", "rt_hip_frame_enqueue_g16", "rt_hip_frame_finish", "rt_hip_comm_unique_id", "rt_hip_comm_init", "rt_hip_comm_destroy", "rt_hip_render_frame_multi_device", "rt_hip_frame_multi_enqueue_device", "rt_hip_frames_multi_enqueue_device", "rt_hip_tiles_packed_enqueue_device", "rt_hip_tiles_packed_batch_enqueue_device",
     "rt_hip_photon_generate_multi", "rt_hip_set_model_mats", "rt_hip_photon_generate", "rt_hip_photon_get", "rt_hip_get_tuning", "rt_hip_set_tuning", "rt_hip_invalidate", "rt_hip_photon_lookup_device", "rt_hip_photon_lookup",
 ]
 
@@ -176,6 +176,8 @@ def load_library() -> C.CDLL:
     L.rt_hip_comm_destroy.argtypes = [P]
     L.rt_hip_render_frame_multi_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_frame_multi_enqueue_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_frames_multi_enqueue_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P]
+    L.rt_hip_tiles_packed_batch_enqueue_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_tiles_packed_enqueue_device.argtypes = [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
     L.rt_hip_photon_generate_multi.argtypes = [P, C.c_int, C.POINTER(C.c_int64)]
     L.rt_hip_get_tuning.argtypes = [P, C.POINTER(Tuning)]
@@ -559,9 +561,23 @@ class RtHip:
         """rt_hip_frame_multi_enqueue_device: the split frame queued without waiting; frame_finish() completes the oldest."""
         self._ck(self.lib.rt_hip_frame_multi_enqueue_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, tile, _dptr(d_rgba)))
 
+    def frames_multi_enqueue_device(self, d_pos_list, d_nrm_list, w, h, tile, d_rgba_list):
+        """rt_hip_frames_multi_enqueue_device: several split frames as ONE pipeline entry (one pass of launches, one all-gather)."""
+        n = len(d_pos_list)
+        arr = C.c_void_p * n
+        self._ck(self.lib.rt_hip_frames_multi_enqueue_device(self.h, arr(*[_dptr(t) for t in d_pos_list]), arr(*[_dptr(t) for t in d_nrm_list]),
+                                                             n, w, h, tile, arr(*[_dptr(t) for t in d_rgba_list])))
+
     def tiles_packed_enqueue_device(self, d_pos_rgb, d_nrm_rgba, w, h, tile, rank, nranks, d_packed):
         """rt_hip_tiles_packed_enqueue_device: one frame's packed share queued without waiting; frame_finish() completes the oldest."""
         self._ck(self.lib.rt_hip_tiles_packed_enqueue_device(self.h, _dptr(d_pos_rgb), _dptr(d_nrm_rgba), w, h, tile, rank, nranks, _dptr(d_packed)))
+
+    def tiles_packed_batch_enqueue_device(self, d_pos_list, d_nrm_list, w, h, tile, rank, nranks, d_packed_list):
+        """rt_hip_tiles_packed_batch_enqueue_device: several frames' packed shares as one pipeline entry."""
+        n = len(d_pos_list)
+        arr = C.c_void_p * n
+        self._ck(self.lib.rt_hip_tiles_packed_batch_enqueue_device(self.h, arr(*[_dptr(t) for t in d_pos_list]), arr(*[_dptr(t) for t in d_nrm_list]),
+                                                                   n, w, h, tile, rank, nranks, arr(*[_dptr(t) for t in d_packed_list])))
 
     def photon_generate_multi(self, per_light):
         stored = C.c_int64(0)

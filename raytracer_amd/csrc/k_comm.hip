@@ -178,56 +178,75 @@ int rt_hip_render_frame_multi_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rg
 }
 
 // The same frame split, queued without waiting (the frame pipeline of rt_hip_frame_enqueue_device, rt_hip_frame_finish
-// completes the oldest frame): the rank's tiles are shaded on the lane the frame is dealt to (tuning.frame_streams), and the
-// all-gather and the unpack follow on a stream of their own, in frame order on every rank -- so the next frame's kernels
+// completes the oldest entry): the rank's tiles are shaded on the lane the entry is dealt to (tuning.frame_streams), and the
+// all-gather and the unpack follow on a stream of their own, in entry order on every rank -- so the next entry's kernels
 // start at once and fill the machine under the tail of this one's, which is what a split frame needs: its launches are
-// short and each as long as its slowest wave.  Exactly one all-gather per call, queued during the call, on every path.
-int rt_hip_frame_multi_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
-                                      int height, int tile, uint8_t* d_rgba_out)
+// short and each as long as its slowest wave.  For the same reason an entry may hold SEVERAL frames (nframes): one pass of
+// launches shades this rank's tiles of all of them, one all-gather carries all their chunks ([rank][frame][chunk] on
+// arrival), one unpack per frame -- with the frame split N ways, N / 2 frames per entry keep the launches as large as half
+// a frame's.  Exactly one all-gather per call, queued during the call, on every path.
+int rt_hip_frames_multi_enqueue_device(rt_hip_ctx* ctx, const float* const* d_gbuf_pos_rgb, const float* const* d_gbuf_nrm_rgba,
+                                       int nframes, int width, int height, int tile, uint8_t* const* d_rgba_out)
 {
 	if (!ctx) { rt_set_error("null context"); return RT_HIP_ERR_ARG; }
 	RT_HIP_CHECK(hipSetDevice(ctx->cfg.device));
 	if (ctx->scene_dirty) { rt_set_error("scene changed: call rt_hip_update() before tracing"); return RT_HIP_ERR_STATE; }
 	if (!ctx->comm) { rt_set_error("no communicator: call rt_hip_comm_init first"); return RT_HIP_ERR_STATE; }
-	if (width <= 0 || height <= 0 || !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_rgba_out || tile <= 0 || tile % 8 != 0 || tile > 1024) {
-		rt_set_error("bad arguments (the tile size must be a positive multiple of 8)");
+	if (width <= 0 || height <= 0 || !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_rgba_out || tile <= 0 || tile % 8 != 0 || tile > 1024 ||
+	    nframes < 1 || nframes > RT_MAX_BATCH) {
+		rt_set_error("bad arguments (1..%d frames; the tile size must be a positive multiple of 8)", RT_MAX_BATCH);
 		return RT_HIP_ERR_ARG;
 	}
+	for (int f = 0; f < nframes; ++f)
+		if (!d_gbuf_pos_rgb[f] || !d_gbuf_nrm_rgba[f] || !d_rgba_out[f]) { rt_set_error("frame %d: null buffer", f); return RT_HIP_ERR_ARG; }
 	int slot = 0;
 	RT_CHECK(rt_pipeline_slot(ctx, &slot));
 	const int rank = ctx->comm_rank, nranks = ctx->comm_nranks;
 	const int64_t most_tiles = max_owned_tiles(width, height, tile, nranks);
 	const size_t chunk = (size_t)most_tiles * tile * tile * 4;
-	// Only frames the sync-free driver takes with no level able to overflow its bound (such a frame would have to be redone
+	// Only entries the sync-free driver takes with no level able to overflow its bound (such a frame would have to be redone
 	// after its tiles had been sent).  Decided from what the LARGEST share of any rank needs, so that every rank decides alike:
 	// a rank that returned here while the others queued their all-gather would leave them waiting.
 	const int bounces = ctx->cfg.bounces;
 	if (ctx->cfg.use_photon_map || ctx->tuning.frame_sync || (int)ctx->lights.size() > 30 || bounces < 1 || bounces > 8 ||
-	    ((most_tiles * tile * tile) << (bounces - 1)) > ((int64_t)1 << 23)) {
-		rt_set_error("a frame of %d x %d texels split %d ways with this configuration cannot be enqueued: use rt_hip_render_frame_multi_device", width, height, nranks);
+	    ((most_tiles * tile * tile * nframes) << (bounces - 1)) > ((int64_t)1 << 23)) {
+		rt_set_error("%d frame(s) of %d x %d texels split %d ways with this configuration cannot be enqueued: fewer frames per call, or rt_hip_render_frame_multi_device",
+		             nframes, width, height, nranks);
 		return RT_HIP_ERR_LIMIT;
 	}
 	if (!ctx->comm_stream) RT_HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
 	PendingFrame* pf = &ctx->pending[slot];
 	if (!pf->ev_done) RT_HIP_CHECK(hipEventCreateWithFlags(&pf->ev_done, hipEventDisableTiming));
 	if (!pf->ev_down) RT_HIP_CHECK(hipEventCreateWithFlags(&pf->ev_down, hipEventDisableTiming));
-	// the slot's chunks are free: the frame that used them last has been finished
+	// the slot's chunks are free: the entry that used them last has been finished
 	DevBuf& send = ctx->d_mg_send_slot[slot];
 	DevBuf& recv = ctx->d_mg_recv_slot[slot];
-	if (send.cap < chunk) {
-		RT_CHECK(send.reserve(chunk));
+	const size_t mine = chunk * nframes;   // this rank's chunks of the entry's frames, one after the other
+	if (send.cap < mine) {
+		RT_CHECK(send.reserve(mine));
 		RT_HIP_CHECK(hipMemsetAsync(send.p, 0, send.cap, ctx->stream));  // the padding of edge tiles is never written
 		RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 	}
-	RT_CHECK(recv.reserve(chunk * nranks));
-	RT_CHECK(rt_frame_enqueue(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, send.as<uint8_t>(), tile, rank, nranks, 1));
+	RT_CHECK(recv.reserve(mine * nranks));
+	uint8_t* chunks[RT_MAX_BATCH];
+	for (int f = 0; f < nframes; ++f) chunks[f] = send.as<uint8_t>() + (size_t)f * chunk;
+	RT_CHECK(rt_frames_enqueue(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, nframes, width, height, chunks, tile, rank, nranks, 1));
 	RT_HIP_CHECK(hipEventRecord(pf->ev_done, pf->stream));
 	RT_HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, pf->ev_done, 0));
-	RT_NCCL_CHECK(g_rccl.AllGather(send.p, recv.p, chunk, ncclUint8, (ncclComm_t)ctx->comm, ctx->comm_stream));
-	RT_CHECK(rt_unpack_chunks(ctx, recv.as<uint8_t>(), (int64_t)chunk, width, height, tile, nranks, d_rgba_out, ctx->comm_stream));
+	RT_NCCL_CHECK(g_rccl.AllGather(send.p, recv.p, mine, ncclUint8, (ncclComm_t)ctx->comm, ctx->comm_stream));
+	for (int f = 0; f < nframes; ++f)
+		RT_CHECK(rt_unpack_chunks(ctx, recv.as<uint8_t>() + (size_t)f * chunk, (int64_t)chunk, width, height, tile, nranks, d_rgba_out[f],
+		                          ctx->comm_stream, (int64_t)mine));
 	RT_HIP_CHECK(hipEventRecord(pf->ev_down, ctx->comm_stream));
 	pf->comm = true;
 	return RT_HIP_OK;
+}
+
+int rt_hip_frame_multi_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_rgb, const float* d_gbuf_nrm_rgba, int width,
+                                      int height, int tile, uint8_t* d_rgba_out)
+{
+	if (!d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_rgba_out) { rt_set_error("bad arguments"); return RT_HIP_ERR_ARG; }
+	return rt_hip_frames_multi_enqueue_device(ctx, &d_gbuf_pos_rgb, &d_gbuf_nrm_rgba, 1, width, height, tile, &d_rgba_out);
 }
 
 // PhotonMap::generate sharded by photon index: this rank emits its contiguous range of the global index

@@ -1363,7 +1363,8 @@ __global__ __launch_bounds__(BLOCK) void k_tiles_pack(uint32_t* __restrict__ fra
 struct ChunkLists {
 	int offset[RT_MAX_BATCH + 1];  // rank r's tile ids are all_tiles[offset[r] .. offset[r + 1])
 };
-__global__ __launch_bounds__(BLOCK) void k_unpack_chunks(const uint32_t* __restrict__ chunks, int64_t chunk_pixels,
+// (rank_stride: pixels from one rank's chunk to the next; larger than chunk_pixels when every rank sent several frames' chunks)
+__global__ __launch_bounds__(BLOCK) void k_unpack_chunks(const uint32_t* __restrict__ chunks, int64_t chunk_pixels, int64_t rank_stride,
                                                          int nranks, ChunkLists cl, const int* __restrict__ all_tiles,
                                                          int w, int h, int tile, uint32_t* __restrict__ frame)
 {
@@ -1376,16 +1377,17 @@ __global__ __launch_bounds__(BLOCK) void k_unpack_chunks(const uint32_t* __restr
 	const int tiles_x = (w + tile - 1) / tile;
 	const int id = all_tiles[cl.offset[r] + kt], k = (int)(local % t2);
 	const int x = (id % tiles_x) * tile + k % tile, y = (id / tiles_x) * tile + k / tile;
-	if (x < w && y < h) frame[(size_t)y * w + x] = chunks[p];
+	if (x < w && y < h) frame[(size_t)y * w + x] = chunks[(int64_t)r * rank_stride + local];
 }
 
 }  // namespace
 
 // ================================================================================================
 int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int w, int h, int tile, int nranks,
-                     uint8_t* d_frame, hipStream_t st)
+                     uint8_t* d_frame, hipStream_t st, int64_t rank_stride_bytes)
 {
 	if (!st) st = ctx->stream;
+	if (rank_stride_bytes <= 0) rank_stride_bytes = chunk_bytes;
 	const int key[4] = {w, h, tile, nranks};
 	const int tiles_x = (w + tile - 1) / tile, tiles_y = (h + tile - 1) / tile;
 	if (memcmp(key, ctx->all_tiles_key, sizeof(key)) != 0 || !ctx->d_all_tiles.p) {
@@ -1412,7 +1414,8 @@ int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_byt
 	}
 	const int64_t n = chunk_pixels * nranks;
 	hipLaunchKernelGGL(k_unpack_chunks, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st,
-	                   (const uint32_t*)d_chunks, chunk_pixels, nranks, cl, ctx->d_all_tiles.as<int>(), w, h, tile, (uint32_t*)d_frame);
+	                   (const uint32_t*)d_chunks, chunk_pixels, rank_stride_bytes / 4, nranks, cl, ctx->d_all_tiles.as<int>(), w, h, tile,
+	                   (uint32_t*)d_frame);
 	RT_HIP_CHECK(hipGetLastError());
 	return RT_HIP_OK;
 }
@@ -2272,21 +2275,26 @@ int rt_pipeline_slot(rt_hip_ctx* ctx, int* slot)
 	return RT_HIP_OK;
 }
 
-int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba, int tile, int rank,
-                     int nranks, int packed)
+// `nframes` frames of one size as ONE pending entry of the pipeline: a single pass of launches shades all of them (the level
+// arrays hold the frames' nodes one after the other), rt_frame_finish completes and accounts for the whole batch.
+int rt_frames_enqueue(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w, int h,
+                      uint8_t* const* d_rgba, int tile, int rank, int nranks, int packed)
 {
 	int slot = 0;
 	RT_CHECK(rt_pipeline_slot(ctx, &slot));
+	if (nframes < 1 || nframes > RT_MAX_BATCH) { rt_set_error("1..%d frames in a batch", RT_MAX_BATCH); return RT_HIP_ERR_LIMIT; }
 	if (ctx->cfg.bounces <= 0 || ctx->cfg.bounces > 8) { rt_set_error("bounces must be 1..8"); return RT_HIP_ERR_LIMIT; }
 	if ((int)ctx->lights.size() > 32) { rt_set_error("more than 32 lights"); return RT_HIP_ERR_LIMIT; }
 	if ((int64_t)((w + 7) & ~7) * ((h + 7) & ~7) > (int64_t)1 << 26) { rt_set_error("frame larger than 2^26 texels"); return RT_HIP_ERR_LIMIT; }
 	PendingFrame* pf = &ctx->pending[slot];
 	FrameSet fs;
 	memset(&fs, 0, sizeof(fs));
-	fs.nframes = 1;
+	fs.nframes = nframes;
 	fs.packed = packed;
-	fs.pos[0] = d_pos_rgb; fs.nrm[0] = d_nrm_rgba; fs.rgba[0] = d_rgba;
-	fs.uv[0] = ctx->frame_uv_count > 0 ? ctx->frame_uv[0] : nullptr;
+	for (int f = 0; f < nframes; ++f) {
+		fs.pos[f] = d_pos_rgb[f]; fs.nrm[f] = d_nrm_rgba[f]; fs.rgba[f] = d_rgba[f];
+		fs.uv[f] = f < ctx->frame_uv_count ? ctx->frame_uv[f] : nullptr;
+	}
 	pf->fs = fs; pf->w = w; pf->h = h; pf->tile = tile; pf->rank = rank; pf->nranks = nranks; pf->packed = packed;
 	pf->comm = false;
 	pf->stream = ctx->stream;
@@ -2313,15 +2321,25 @@ int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm
 		// photon-mapped frames, more than 30 lights, frames too large to size by bounds: rendered here and now
 		if (ctx->pending_count > 0) { rt_set_error("this frame needs the synchronous driver: finish the enqueued frame first"); return RT_HIP_ERR_STATE; }
 		if (packed) { rt_set_error("a packed frame that needs the synchronous driver cannot be enqueued"); return RT_HIP_ERR_STATE; }
-		RT_CHECK(render_frame_sync(ctx, d_pos_rgb, d_nrm_rgba, fs.uv[0], w, h, tile, rank, nranks, d_rgba));
+		int64_t rays = 0;
+		for (int f = 0; f < nframes; ++f) {
+			RT_CHECK(render_frame_sync(ctx, fs.pos[f], fs.nrm[f], fs.uv[f], w, h, tile, rank, nranks, fs.rgba[f]));
+			rays += ctx->last_frame_rays;
+		}
 		pf->complete = true;
-		pf->rays = ctx->last_frame_rays;
+		pf->rays = rays;
 		pf->stream = ctx->stream;
 	}
 	pf->used = true;
 	++ctx->pending_count;
 	++ctx->frame_seq;
 	return RT_HIP_OK;
+}
+
+int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba, int tile, int rank,
+                     int nranks, int packed)
+{
+	return rt_frames_enqueue(ctx, &d_pos_rgb, &d_nrm_rgba, 1, w, h, &d_rgba, tile, rank, nranks, packed);
 }
 
 int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
@@ -2334,8 +2352,12 @@ int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays)
 	ctx->frame_redone = overflowed;
 	if (overflowed) {
 		// exceptional: the frame again, on the driver that sizes every level on the host (behind whatever is still queued)
-		RT_CHECK(render_frame_sync(ctx, pf->fs.pos[0], pf->fs.nrm[0], pf->fs.uv[0], pf->w, pf->h, pf->tile, pf->rank, pf->nranks, pf->fs.rgba[0]));
-		pf->rays = ctx->last_frame_rays;
+		int64_t rays = 0;
+		for (int f = 0; f < pf->fs.nframes; ++f) {
+			RT_CHECK(render_frame_sync(ctx, pf->fs.pos[f], pf->fs.nrm[f], pf->fs.uv[f], pf->w, pf->h, pf->tile, pf->rank, pf->nranks, pf->fs.rgba[f]));
+			rays += ctx->last_frame_rays;
+		}
+		pf->rays = rays;
 	}
 	if (out_rays) *out_rays = pf->rays;
 	ctx->last_frame_rays = pf->rays;

@@ -915,6 +915,21 @@ int rt_hip_tiles_packed_enqueue_device(rt_hip_ctx* ctx, const float* d_gbuf_pos_
 	return rt_frame_enqueue(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, width, height, d_packed_out, tile, rank, nranks, 1);
 }
 
+// ... and the packed shares of several frames as one pipeline entry (one pass of launches for all of them)
+int rt_hip_tiles_packed_batch_enqueue_device(rt_hip_ctx* ctx, const float* const* d_gbuf_pos_rgb, const float* const* d_gbuf_nrm_rgba,
+                                             int nframes, int width, int height, int tile, int rank, int nranks, uint8_t* const* d_packed_out)
+{
+	RT_CHECK(check_ready(ctx));
+	if (width <= 0 || height <= 0 || nframes <= 0 || nframes > RT_MAX_BATCH || !d_gbuf_pos_rgb || !d_gbuf_nrm_rgba || !d_packed_out || tile <= 0 ||
+	    tile % 8 != 0 || nranks <= 1 || nranks > RT_MAX_BATCH || rank < 0 || rank >= nranks) {
+		rt_set_error("bad arguments (packed output needs 1 < nranks <= 16, tile %% 8 == 0 and 1..16 frames)");
+		return RT_HIP_ERR_ARG;
+	}
+	for (int f = 0; f < nframes; ++f)
+		if (!d_gbuf_pos_rgb[f] || !d_gbuf_nrm_rgba[f] || !d_packed_out[f]) { rt_set_error("frame %d: null buffer", f); return RT_HIP_ERR_ARG; }
+	return rt_frames_enqueue(ctx, d_gbuf_pos_rgb, d_gbuf_nrm_rgba, nframes, width, height, d_packed_out, tile, rank, nranks, 1);
+}
+
 int rt_hip_unpack_chunks_device(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int width, int height, int tile,
                                 int nranks, uint8_t* d_frame_rgba)
 {

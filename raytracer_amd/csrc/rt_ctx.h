@@ -302,6 +302,8 @@ int rt_render_frame(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_
                     int rank, int nranks, uint8_t* d_rgba);
 int rt_frame_enqueue(rt_hip_ctx* ctx, const float* d_pos_rgb, const float* d_nrm_rgba, int w, int h, uint8_t* d_rgba,
                      int tile = 64, int rank = 0, int nranks = 1, int packed = 0);
+int rt_frames_enqueue(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w, int h,
+                      uint8_t* const* d_rgba, int tile = 64, int rank = 0, int nranks = 1, int packed = 0);  // a batch = one pending entry
 int rt_pipeline_slot(rt_hip_ctx* ctx, int* slot);  // the ring slot the next enqueued frame takes, or RT_HIP_ERR_STATE when the pipeline is full
 FrameLane rt_frame_lane(rt_hip_ctx* ctx, int lane);
 int rt_frame_finish(rt_hip_ctx* ctx, int64_t* out_rays);
@@ -309,7 +311,7 @@ int rt_launch_decode_g16(rt_hip_ctx* ctx, const uint16_t* d_nrm16, const uint16_
 int rt_render_frames(rt_hip_ctx* ctx, const float* const* d_pos_rgb, const float* const* d_nrm_rgba, int nframes, int w,
                      int h, int tile, int rank, int nranks, uint8_t* const* d_rgba, int packed = 0);
 int rt_unpack_chunks(rt_hip_ctx* ctx, const uint8_t* d_chunks, int64_t chunk_bytes, int w, int h, int tile, int nranks,
-                     uint8_t* d_frame, hipStream_t st = nullptr);  // nullptr: ctx->stream
+                     uint8_t* d_frame, hipStream_t st = nullptr, int64_t rank_stride_bytes = 0);  // nullptr: ctx->stream; 0: the chunks lie back to back
 
 // ---- k_noalloc.hip -------------------------------------------------------------------------------
 int rt_noalloc_setup(int device);  // once per device, that device current

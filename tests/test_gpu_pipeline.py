@@ -241,4 +241,25 @@ def test_packed_shares_through_the_pipeline_equal_the_blocking_entry():
     assert torch.equal(out, whole)
     with pytest.raises(rt.RtHipError):
         enq(g, d_p, d_n, w, h, tile, 0, 1, got[:chunk])       # one rank: nothing to pack
+    # entries of several frames (rt_hip_tiles_packed_batch_enqueue_device): a second frame beside the first, every rank's
+    # entry of (frame A, frame B, frame A) side by side on the three lanes
+    n2 = torch.zeros_like(d_n); p2 = torch.zeros_like(d_p)
+    g.render_gbuffer_device(sc.fov - 0.1, w, h, n2, p2)
+    ref2 = torch.zeros(nranks * chunk, dtype=torch.uint8, device="cuda")
+    rays2 = []
+    g.set_tuning(frame_streams=1)
+    for r in range(nranks):
+        g.render_tiles_packed_device([p2], [n2], w, h, tile, r, nranks, [ref2[r * chunk:(r + 1) * chunk]])
+        rays2.append(g.last_frame_rays())
+    g.set_tuning(frame_streams=3)
+    enqb = rt.RtHip.tiles_packed_batch_enqueue_device.__wrapped__
+    gots = [[torch.zeros(chunk, dtype=torch.uint8, device="cuda") for _ in range(3)] for _ in range(nranks)]
+    torch.cuda.synchronize()
+    for r in range(nranks):
+        enqb(g, [d_p, p2, d_p], [d_n, n2, d_n], w, h, tile, r, nranks, gots[r])
+    assert [g.frame_finish() for _ in range(nranks)] == [2 * rays[r] + rays2[r] for r in range(nranks)]
+    g.sync()
+    for r in range(nranks):
+        assert torch.equal(gots[r][0], ref[r * chunk:(r + 1) * chunk]) and torch.equal(gots[r][2], ref[r * chunk:(r + 1) * chunk])
+        assert torch.equal(gots[r][1], ref2[r * chunk:(r + 1) * chunk])
     g.close()
