@@ -552,6 +552,77 @@ __device__ __forceinline__ void wave_shell_sweep(uint32_t* mark, const GridDesc&
 	}
 }
 
+// wave_shell_sweep for TWO points at once (neighbours in the queue, i.e. on the screen: A and B a fraction of a cell apart).
+// One walk of the grid rows, one flattening of the runs and one load per photon serve both points, and the distance
+// arithmetic runs two points per instruction (packed FP32: the photon's coordinate against (A, B) -- the same IEEE
+// operations per component, in dot3's order, so each point gets the bits it would get alone).  The walk is made for the
+// pair's midpoint C with en >= |A - C| = |B - C|: a cell within 0.999 r - en of C is interior to both spheres (counted
+// from the table), a cell beyond r + en is outside both, the photons between are tested against both.  bound_l as in
+// wave_shell_sweep, for C: the farthest interior photon is within sqrt(bound) + en of either point.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wave_shell_sweep_pair(uint32_t* mark, const GridDesc& gd, const uint32_t* __restrict__ cs, const float4* __restrict__ pos,
+                                                      f3 C, f3 A, f3 B, float radius, float en, float r2, int& common_l, int& nca_l, int& ncb_l,
+                                                      uint32_t& mxa_u, uint32_t& mxb_u, float& bound_l)
+{
+	const float rho = (radius + en) * 1.0001f + 1e-30f;
+	const float rin = radius * 0.999f - en;
+	const int y0 = cell_coord(C.y - rho, gd.mn[1], gd.inv_cell, gd.dim[1]), y1 = cell_coord(C.y + rho, gd.mn[1], gd.inv_cell, gd.dim[1]);
+	const int z0 = cell_coord(C.z - rho, gd.mn[2], gd.inv_cell, gd.dim[2]), z1 = cell_coord(C.z + rho, gd.mn[2], gd.inv_cell, gd.dim[2]);
+	const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+	const int lane = lane_id();
+	const uint32_t ny_magic = row_div_magic(ny);
+	const bool rows_small = nrows < 65536 && ny <= 4096 && ny > 1;
+	const float slack = gd.cell * 1e-3f;
+	const v2f PX = {A.x, B.x}, PY = {A.y, B.y}, PZ = {A.z, B.z};
+	for (int base = 0; base < nrows; base += 64) {
+		const int row = base + lane;
+		uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+		if (row < nrows) {
+			const int zr = row_div(row, ny, ny_magic, rows_small);
+			const int y = y0 + (row - zr * ny), z = z0 + zr;
+			int x0, x1;
+			if (row_chord(gd, C, rho, y, z, x0, x1)) {
+				const uint32_t rb = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
+				a0 = cs[rb + x0]; a1 = cs[rb + x1 + 1];
+				const bool border = y == 0 || y == gd.dim[1] - 1 || z == 0 || z == gd.dim[2] - 1;
+				if (a1 > a0 && !border) {
+					const float ylo = gd.mn[1] + (float)y * gd.cell, zlo = gd.mn[2] + (float)z * gd.cell;
+					const float dyf = fmaxf(fabsf(ylo - C.y), fabsf(ylo + gd.cell - C.y)) + slack;
+					const float dzf = fmaxf(fabsf(zlo - C.z), fabsf(zlo + gd.cell - C.z)) + slack;
+					const float h2 = rin * rin - (dyf * dyf + dzf * dzf);
+					if (h2 > 0.0f) {
+						const float half = bound_sqrtf(h2) * 0.9999f - slack;
+						int xi0 = (int)ceilf((C.x - half - gd.mn[0]) * gd.inv_cell + 1e-3f);
+						int xi1 = (int)floorf((C.x + half - gd.mn[0]) * gd.inv_cell - 1e-3f) - 1;
+						xi0 = max(xi0, max(x0, 1)); xi1 = min(xi1, min(x1, gd.dim[0] - 2));
+						if (xi0 <= xi1) {
+							const uint32_t i0 = cs[rb + xi0], i1 = cs[rb + xi1 + 1];
+							const float dxf = fmaxf(fabsf(gd.mn[0] + (float)xi0 * gd.cell - C.x),
+							                        fabsf(gd.mn[0] + (float)(xi1 + 1) * gd.cell - C.x)) + slack;
+							const float far2 = (dxf * dxf + (dyf * dyf + dzf * dzf)) * 1.0001f;  // >= |q - C|^2 in the run
+							common_l += (int)(i1 - i0);
+							b0 = i1; b1 = a1; a1 = i0;
+							if (i1 > i0) bound_l = fmaxf(bound_l, far2);
+						}
+					}
+				}
+			}
+		}
+		auto visit = [&](const float4 q, uint32_t, bool act) {
+			const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+			const v2f dx = qx - PX, dy = qy - PY, dz = qz - PZ;
+			const v2f l2 = dx * dx + (dy * dy + dz * dz);   // dot3's order
+			const bool ina = act && l2.x < r2, inb = act && l2.y < r2;
+			nca_l += ina ? 1 : 0;
+			ncb_l += inb ? 1 : 0;
+			mxa_u = max(mxa_u, ina ? __float_as_uint(l2.x) : 0u);
+			mxb_u = max(mxb_u, inb ? __float_as_uint(l2.y) : 0u);
+		};
+		wave_visit_runs<true>(mark, pos, a0, a1, visit);
+		if (__ballot(b1 > b0)) wave_visit_runs<true>(mark, pos, b0, b1, visit);
+	}
+}
+
 // PhotonMap::radiance_estimate (rt_photon_map.cpp:149-208), one lane per shading point.
 //   pass 1   all photons within `radius`: their number, max_dist2 over ALL of them (:159-169), and a
 //            64-bin histogram of the squared distance over [0, r^2)
@@ -752,7 +823,7 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                            float2* __restrict__ p1, const int* __restrict__ sub_queue,
                                                            const int* __restrict__ sub_count, GridDesc gdc,
                                                            const uint32_t* __restrict__ cell_start_c,
-                                                           const float4* __restrict__ pos_c, uint32_t medium)
+                                                           const float4* __restrict__ pos_c, uint32_t medium, float pair_extent)
 {
 	__shared__ uint32_t s_hist[SEL_BINS];
 	__shared__ uint32_t s_list[SEL_LIST], s_lslot[SEL_LIST];
@@ -773,7 +844,64 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 	// PHASE 1 runs several waves per workgroup, each on a point of its own: neighbours in the queue, hence in the frame,
 	// read the same photons at the same time through one L1
 	const int nw = PHASE == 1 ? RT_GATHER_P1_WAVES : 1, wv = PHASE == 1 ? (int)(threadIdx.x >> 6) : 0;
-	for (int hq = (int)xcd_block_index(xcd_chunk) * nw + wv; hq < nheavy; hq += gridDim.x * nw) {
+	// PHASE 1 with pair_extent > 0: a wave takes queue entries 2 j and 2 j + 1 per round -- together (wave_shell_sweep_pair)
+	// when both walk the fine grid's shell and lie within pair_extent of each other, else one after the other as before
+	const bool pairs = PHASE == 1 && SHELL && pair_extent > 0.0f && !sub_queue;
+	const int per_round = pairs ? 2 : 1;
+	const int nrounds = (nheavy + per_round - 1) / per_round;
+	for (int round = (int)xcd_block_index(xcd_chunk) * nw + wv; round < nrounds; round += gridDim.x * nw) {
+		if (pairs && 2 * round + 1 < nheavy) {
+			const int hq = 2 * round;
+			const int ia = __builtin_amdgcn_readfirstlane(heavy_queue[hq]), ib = __builtin_amdgcn_readfirstlane(heavy_queue[hq + 1]);
+			f3 A, B;
+			A.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)ia + 0])));
+			A.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)ia + 1])));
+			A.z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)ia + 2])));
+			B.x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)ib + 0])));
+			B.y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)ib + 1])));
+			B.z = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, qpos[3 * (size_t)ib + 2])));
+			const f3 C = mk3(0.5f * (A.x + B.x), 0.5f * (A.y + B.y), 0.5f * (A.z + B.z));
+			const f3 da = A - C, db = B - C;
+			const float en = bound_sqrtf(fmaxf(dot3(da, da), dot3(db, db))) * 1.0001f + radius * 1e-6f;
+			bool both = en <= pair_extent;   // false for a NaN
+			if (both && medium > 0u) {
+				// neither point may be one that reads its (small) neighbourhood from the coarse grid instead: the cube about the
+				// midpoint, widened by en, holds both points' cubes
+				const float rho = (radius + en) * 1.0001f + 1e-30f;
+				const int y0 = cell_coord(C.y - rho, gdc.mn[1], gdc.inv_cell, gdc.dim[1]), y1 = cell_coord(C.y + rho, gdc.mn[1], gdc.inv_cell, gdc.dim[1]);
+				const int z0 = cell_coord(C.z - rho, gdc.mn[2], gdc.inv_cell, gdc.dim[2]), z1 = cell_coord(C.z + rho, gdc.mn[2], gdc.inv_cell, gdc.dim[2]);
+				const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+				uint32_t pop = 0;
+				for (int row = lane; row < nrows; row += 64) {
+					const int zr = row / ny, y = y0 + (row - zr * ny), z = z0 + zr;
+					int x0, x1;
+					if (row_chord(gdc, C, rho, y, z, x0, x1)) {
+						const uint32_t rb = (uint32_t)((z * gdc.dim[1] + y) * gdc.dim[0]);
+						pop += cell_start_c[rb + x1 + 1] - cell_start_c[rb + x0];
+					}
+				}
+				both = wave_sum_u(pop) > medium;
+			}
+			if (__builtin_amdgcn_readfirstlane(both ? 1 : 0)) {
+				int common_l = 0, nca_l = 0, ncb_l = 0;
+				uint32_t mxa_u = 0u, mxb_u = 0u;
+				float bound_l = 0.0f;
+				wave_shell_sweep_pair(mark, gd, cell_start, pos, C, A, B, radius, en, r2, common_l, nca_l, ncb_l, mxa_u, mxb_u, bound_l);
+				const int common = wave_sum_i(common_l);
+				const int nca = wave_sum_i(nca_l) + common, ncb = wave_sum_i(ncb_l) + common;
+				const float mxa = wave_max_f(__uint_as_float(mxa_u)), mxb = wave_max_f(__uint_as_float(mxb_u));
+				const float bw = wave_max_f(bound_l);
+				const float reach = bound_sqrtf(bw) * 1.0001f + en;
+				const float far_in = bw > 0.0f ? reach * reach * 1.0001f : 0.0f;   // no interior photon is farther than this from A or B
+				if (!(far_in > mxa) && !(far_in > mxb)) {
+					if (lane == 0) { p1[hq] = make_float2(__int_as_float(nca), mxa); p1[hq + 1] = make_float2(__int_as_float(ncb), mxb); }
+					continue;
+				}
+			}
+		}
+		for (int sub = 0; sub < per_round; ++sub) {
+		const int hq = per_round * round + sub;
+		if (hq >= nheavy) break;
 		const int h = sub_queue ? __builtin_amdgcn_readfirstlane(sub_queue[hq]) : hq;
 		const int i = __builtin_amdgcn_readfirstlane(heavy_queue[h]);
 		f3 P, N;
@@ -1017,6 +1145,7 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 		}
 		result = div3(result, gc.two_pi * max_dist2);
 		if (lane == 0) st3(rgb + 3 * (size_t)i, result);
+		}   // sub
 	}
 }
 
@@ -1389,18 +1518,19 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 			const int blocks1 = ((std::min(npts, 64 * 1024) + RT_GATHER_P1_WAVES - 1) / RT_GATHER_P1_WAVES + unit1 - 1) / unit1 * unit1;
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 1>), dim3(blocks1), dim3(64 * RT_GATHER_P1_WAVES), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk > 0 ? chunk1 : 0, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium,
+			                   ctx->photon_cell_f * (float)ctx->tuning.gather_pair * 0.01f);
 			// the usual heavy point in the lean kernel; what it declines, in the general one
 			hipLaunchKernelGGL(k_photon_select_common, dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), d_pos, d_nrm, heavy_queue, heavy_count, count,
 			                   radius, gc, d_rgb, chunk, pass1, sub_queue, sub_count);
 			hipLaunchKernelGGL((k_photon_gather_wave<true, 2>), dim3(waves), dim3(64), 0, ctx->stream, gf, ctx->d_cell_start_f.as<uint32_t>(),
 			                   ctx->d_photons_f.as<float4>(), ctx->d_photon_sorted_f.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)sub_queue, (const int*)sub_count, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)sub_queue, (const int*)sub_count, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium, 0.0f);
 		} else {
 			hipLaunchKernelGGL((k_photon_gather_wave<false, 0>), dim3(waves), dim3(64), 0, ctx->stream, gd, ctx->d_cell_start.as<uint32_t>(),
 			                   ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(), ctx->num_photons, d_pos, d_nrm,
-			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium);
+			                   heavy_queue, heavy_count, count, radius, gc, d_rgb, chunk, pass1, (const int*)nullptr, (const int*)nullptr, gd, ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), medium, 0.0f);
 		}
 		RT_HIP_CHECK(hipGetLastError());
 	}

@@ -100,6 +100,7 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->shadow_prefix_steps = env_int("RT_HIP_SHADOW_PREFIX_STEPS", 24);
 	t->shadow_prefix_min_rays = env_int("RT_HIP_SHADOW_PREFIX_MIN_RAYS", -1);
 	t->frame_streams = env_int("RT_HIP_FRAME_STREAMS", 1);
+	t->gather_pair = env_int("RT_HIP_GATHER_PAIR", 100);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
@@ -125,6 +126,7 @@ void rt_clamp_tuning(rt_hip_ctx* ctx)
 	t.shadow_prefix = std::min(30, std::max(0, t.shadow_prefix));
 	t.shadow_prefix_steps = std::min(1024, std::max(1, t.shadow_prefix_steps));
 	t.frame_streams = std::min(RT_MAX_PENDING, std::max(1, t.frame_streams));
+	t.gather_pair = std::min(100000, std::max(0, t.gather_pair));
 	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;
 }
 

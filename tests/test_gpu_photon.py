@@ -94,6 +94,39 @@ def test_gather_matches_oracle(oracle_cls, count, radius, heavy, medium):
     g.close()
 
 
+@pytest.mark.parametrize("count,radius", [(100, 1.0), (50, 3.0), (400, 3.0)])
+def test_gather_first_pass_two_points_at_once(oracle_cls, count, radius):
+    """tuning.gather_pair: the first pass (count and max_dist2, rt_photon_map.cpp:159-169) for two neighbouring queue
+    entries in one walk, the distances of a photon to both points in packed FP32.  gather_pair = 0 (every point alone),
+    the default width, and a width that pairs whatever is adjacent in the queue: the same bits from all of them (a
+    point's count and max_dist2 do not depend on its partner), and the oracle's values.  gather_medium = 0 sends every
+    point through the shell walk, where the pairs are formed; an odd number of points leaves the last one alone."""
+    import raytracer_amd as rt
+    sc = scenes.cornell()
+    orc = oracle_cls(sc)
+    ph = orc.photon_generate(8000, geometry=0, rng=1, seed=11)
+    nr, po = orc.software_gbuffer(64, 48)
+    pos, nrm, _ = orc.gbuffer_select(nr, po)
+    if pos.shape[0] % 2 == 0:
+        pos, nrm = pos[:-1], nrm[:-1]
+    orc.photon_set(ph)
+    exp = orc.radiance_estimate(pos, nrm, count, radius)
+    ok = ~np.isnan(exp)
+    assert ok.mean() > 0.5
+    outs = {}
+    for pair in (0, 100, 25, 100000):
+        for medium in (0, 4096, 200):
+            g = rt.RtHip(sc, semantics="array", photon_radius=radius, tuning=dict(gather_pair=pair, gather_medium=medium, gather_heavy=0))
+            assert g.tuning()["gather_pair"] == pair
+            g.photon_set(ph)
+            outs[pair, medium] = g.radiance_estimate(pos, nrm, count, radius)
+            g.close()
+    for key, got in outs.items():
+        np.testing.assert_array_equal(np.isnan(exp), np.isnan(got), err_msg=str(key))
+        np.testing.assert_allclose(got[ok], exp[ok], rtol=2e-5, atol=1e-9, err_msg=str(key))
+        np.testing.assert_array_equal(got[ok], outs[0, 0][ok], err_msg=str(key))
+
+
 @pytest.mark.parametrize("medium", [4096, 0], ids=["medium-default", "shell-walk-forced"])
 @pytest.mark.parametrize("heavy", [0, 4000000000], ids=["all-wave", "all-lane"])
 def test_gather_ties_at_the_kth_distance(oracle_cls, heavy, medium):
