@@ -585,7 +585,7 @@ __device__ __forceinline__ void wave_shell_sweep_pair(uint32_t* mark, const Grid
 				const uint32_t rb = (uint32_t)((z * gd.dim[1] + y) * gd.dim[0]);
 				a0 = cs[rb + x0]; a1 = cs[rb + x1 + 1];
 				const bool border = y == 0 || y == gd.dim[1] - 1 || z == 0 || z == gd.dim[2] - 1;
-				if (a1 > a0 && !border) {
+				if (a1 > a0 && !border && rin > 0.0f) {   // (rin <= 0: a pair farther apart than the radius has no common interior)
 					const float ylo = gd.mn[1] + (float)y * gd.cell, zlo = gd.mn[2] + (float)z * gd.cell;
 					const float dyf = fmaxf(fabsf(ylo - C.y), fabsf(ylo + gd.cell - C.y)) + slack;
 					const float dzf = fmaxf(fabsf(zlo - C.z), fabsf(zlo + gd.cell - C.z)) + slack;
