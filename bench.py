@@ -50,8 +50,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 L2_PEAK_GBS = 34500.0            # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s over the 8 XCDs
 L1_PEAK_GBS = 39321.6            # 64 B/clk/CU x 256 CUs x 2.4 GHz
-VALU_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 vector peak (packed / dual-issue FMA on every lane)
-VALU_UNPACKED_TFLOPS = 78.6      # plain per-lane v_fma_f32: what scalar-per-lane ray code can issue
+VALU_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: FP32 vector peak = 2 FLOP x 32 lanes/clk/SIMD x 1024 SIMDs x 2.4 GHz: a wave64 v_fma_f32
+                                 # issues over 2 cycles when more than one wave feeds the SIMD (4 for a wave alone); plain per-lane FMA code can
+                                 # reach it -- packed FP32 takes 4 cycles per instruction and adds nothing (scripts/probes/pk_rate.hip, measured)
 NODE_FLOP, TRI_FLOP = 34.0, 45.0  # per node visit: 12 FMA (24) + 8 min/max + 2 compares for both child boxes; per triangle test: Moeller-Trumbore up to t
 NODE_BYTES = 32.0                # the traversal reads 32-byte quantised nodes (rt_dev.h: QNode)
 NODE_BYTES_SURVEY = 64.0         # SURVEY.md 8d prices a node visit at the 64-byte float node
@@ -565,11 +566,11 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
                                    "coarse-grid cells within the radius, to count the candidates and find max_dist2 (rt_photon_map.cpp:159-169). "
                                    "The kernels do less than that (cells inside the sphere are counted from the cell table, not read) and more "
                                    "(the selection and the sum, not credited)",
-                "frac_unpacked_peak": round(achieved / VALU_UNPACKED_TFLOPS, 4), "peak_unpacked": VALU_UNPACKED_TFLOPS,
                 "algorithmic_cache_GBs": round(visits * GATHER_VISIT_BYTES / (avg_ms * 1e-3) / 1e9, 1),
                 "algorithmic_cache_note": "16 B x photon visits / launch time: served by L1/L2 (neighbouring points read the same cells), not an HBM rate",
-                "bound_note": "vector-ALU issue: the pass is a distance test per photon out of cache-resident cells; the selection passes and "
-                              "the load imbalance between points are why the credited first pass reaches a small fraction of the peak"}
+                "bound_note": "a distance test per photon out of cache-resident cells: the L1 data return (td_busy_frac) and the vector ALU (valu_issue_frac "
+                              "of the slots at 2 cycles per wave64 instruction) together; the selection passes and the load imbalance between points are why "
+                              "the credited first pass reaches a small fraction of the peak"}
     else:
         fused = clo_launches == 0 and rays_clo > 0   # the frame driver folds the closest-hit queues into the shadow launches
         if fused:
@@ -609,7 +610,6 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
                 "any_hit_nodes_per_ray_executed": round(cs_exec["census_nodes_any"] / max(cs_exec["census_rays_any"], 1), 2),
                 "any_hit_tris_per_ray_executed": round(cs_exec["census_tris_any"] / max(cs_exec["census_rays_any"], 1), 2),
                 "shadow_prefix": tun["shadow_prefix"], "shadow_prefix_steps": tun["shadow_prefix_steps"],
-                "frac_unpacked_peak": round(achieved / VALU_UNPACKED_TFLOPS, 4), "peak_unpacked": VALU_UNPACKED_TFLOPS,
                 "algorithmic_cache_GBs_32B_nodes": round(rays_per_launch * bpr32 / sec / 1e9, 1) if avg_ms > 0 else 0.0,
                 "algorithmic_cache_GBs_64B_nodes": round(rays_per_launch * bpr64 / sec / 1e9, 1) if avg_ms > 0 else 0.0,
                 "algorithmic_cache_note": "rays x (node bytes x nodes/ray + 48 x tris/ray + 48): the 32-byte quantised node the kernel reads, and "
@@ -639,9 +639,11 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
             if k in counters:
                 roof[k] = counters[k]
     roof["counters_source"] = counters_note
-    roof.setdefault("bound_note", "per the counters the kernel is limited by vector-ALU issue together with the vector-memory pipeline (TA/TD: each 16 B/lane load "
-                                  "occupies the CU's data return path for 16 cycles whatever the cache hit rate), at two thirds of the lanes active; HBM carries a "
-                                  "few percent of its peak")
+    roof.setdefault("bound_note", "per the counters the tightest resource is the vector-memory return path (td_busy_frac: each 16 B/lane load occupies the CU's "
+                                  "L1 data return for 16 cycles whatever the cache hit rate, and a node visit is two of them per wave, shared by the CU's four "
+                                  "SIMDs), then the waits of each wave's chain of dependent fetches (wait_any_frac); the vector ALU issues valu_issue_frac of the "
+                                  "slots it has at 2 cycles per wave64 instruction (rounds 1-2 quoted twice that: 4 cycles, the rate of a wave alone), at two "
+                                  "thirds of the lanes active; HBM carries a few percent of its peak")
     return roof
 
 
