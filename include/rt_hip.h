@@ -173,7 +173,10 @@ typedef struct rt_hip_tuning {
 	                           *      they lie within this many percent of a fine cell of their midpoint: one walk of the grid, one flattening of
 	                           *      the runs and one load per photon serve both (the distance arithmetic in packed FP32); 0 = every point alone.
 	                           *      Same counts and max_dist2 bit for bit (first pass 3.17 -> 2.69 ms on the C5 frame's level 0). */
-	int reserved[1];
+	int gather_sort;          /* 1    RT_HIP_GATHER_SORT: the wave-per-point gather's queue sorted by the points' positions (Morton order of their
+	                           *      fine-grid cells) before the wave kernels: neighbours in the queue are then neighbours in space whatever order
+	                           *      the caller's points come in (pairs form, each part of the map is read through one XCD's L2).  1: except for
+	                           *      level 0 of a frame (8 x 8 tiles already); 2: always; 0: never.  Results do not depend on it. */
 } rt_hip_tuning;
 
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent

@@ -61,7 +61,7 @@ class Tuning(C.Structure):
     """rt_hip_tuning (include/rt_hip.h): knobs outside the reference's semantics."""
     _fields_ = [("lds_stack_depth", C.c_int), ("xcd_chunk", C.c_int), ("trace_oversub", C.c_int), ("auto_accel", C.c_int),
                 ("ploc_radius", C.c_int), ("frame_sync", C.c_int), ("gather_heavy", C.c_uint32), ("extra_lds_bytes", C.c_int),
-                ("max_bvh_depth", C.c_int), ("refit_max_growth", C.c_float), ("gather_fine", C.c_int), ("gather_xcd_chunk", C.c_int), ("gather_fine_cells", C.c_int), ("gather_medium", C.c_uint32), ("shadow_prefix", C.c_int), ("shadow_prefix_steps", C.c_int), ("shadow_prefix_min_rays", C.c_int), ("frame_streams", C.c_int), ("gather_pair", C.c_int), ("reserved", C.c_int * 1)]
+                ("max_bvh_depth", C.c_int), ("refit_max_growth", C.c_float), ("gather_fine", C.c_int), ("gather_xcd_chunk", C.c_int), ("gather_fine_cells", C.c_int), ("gather_medium", C.c_uint32), ("shadow_prefix", C.c_int), ("shadow_prefix_steps", C.c_int), ("shadow_prefix_min_rays", C.c_int), ("frame_streams", C.c_int), ("gather_pair", C.c_int), ("gather_sort", C.c_int)]
 
 
 UPDATE_NONE, UPDATE_TABLES, UPDATE_REFIT, UPDATE_REBUILD = 0, 1, 2, 3

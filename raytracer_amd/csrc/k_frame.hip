@@ -2148,7 +2148,7 @@ static int render_frame_sync(rt_hip_ctx* ctx, const float* d_pos_rgb, const floa
 			hipLaunchKernelGGL(k_node_points, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, st, geo, n, ctx->d_org.as<float>(),
 			                   ctx->d_dir.as<float>());
 			RT_CHECK(rt_photon_gather(ctx, ctx->d_org.as<float>(), ctx->d_dir.as<float>(), n, ctx->cfg.photon_estimate,
-			                          ctx->cfg.photon_radius, ctx->d_accum.as<float>()));
+			                          ctx->cfg.photon_radius, ctx->d_accum.as<float>(), L == 0));  // level 0: 8 x 8 tiles of the frame
 			photon_rgb = ctx->d_accum.as<float>();
 		} else if (ctx->cfg.do_shadows && sv.num_lights > 0) {
 			RT_CHECK(ctx->d_occ.reserve((size_t)n * 4));

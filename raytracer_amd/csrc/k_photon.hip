@@ -649,13 +649,27 @@ __device__ __forceinline__ int sel_bin(float l2, float lo, float scale)
 	return min(max(b, 0), SEL_BINS - 1);
 }
 
+// 21 bits of x, y, z interleaved (x lowest)
+__device__ __forceinline__ uint64_t spread3_21(uint32_t v)
+{
+	uint64_t x = v & 0x1fffffu;
+	x = (x | (x << 32)) & 0x1f00000000ffffull;
+	x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+	x = (x | (x << 8)) & 0x100f00f00f00f00full;
+	x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+	x = (x | (x << 2)) & 0x1249249249249249ull;
+	return x;
+}
+__device__ __forceinline__ uint64_t morton3_63(uint32_t x, uint32_t y, uint32_t z) { return spread3_21(x) | (spread3_21(y) << 1) | (spread3_21(z) << 2); }
+
 __global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uint32_t* __restrict__ cell_start,
                                                           const float4* __restrict__ pos,
                                                           const float4* __restrict__ payload, int64_t nph,
                                                           const float* __restrict__ qpos, const float* __restrict__ qnrm,
                                                           int npts, int count, float radius, GatherConst gc,
                                                           float* __restrict__ rgb, uint32_t heavy_threshold,
-                                                          int* __restrict__ heavy_queue, int* __restrict__ heavy_count)
+                                                          int* __restrict__ heavy_queue, int* __restrict__ heavy_count,
+                                                          GridDesc gf, uint64_t* __restrict__ heavy_keys)
 {
 	__shared__ uint32_t s_hist[SEL_BINS * GBLOCK];  // doubles as the candidate list (SEL_LIST <= SEL_BINS)
 	uint32_t* hist = s_hist + threadIdx.x;
@@ -675,7 +689,15 @@ __global__ __launch_bounds__(GBLOCK) void k_photon_gather(GridDesc gd, const uin
 			int base = 0;
 			if (lane_id() == 0) base = atomicAdd(heavy_count, (int)__popcll(hm));
 			base = __shfl(base, 0);
-			if (heavy) heavy_queue[base + (int)__popcll(hm & lanemask_lt())] = i;
+			if (heavy) {
+				const int slot = base + (int)__popcll(hm & lanemask_lt());
+				heavy_queue[slot] = i;
+				// the point's place in space (Morton code of its fine-grid cell), for a queue sorted by position (tuning.gather_sort)
+				if (heavy_keys)
+					heavy_keys[slot] = morton3_63((uint32_t)cell_coord(P.x, gf.mn[0], gf.inv_cell, gf.dim[0]),
+					                              (uint32_t)cell_coord(P.y, gf.mn[1], gf.inv_cell, gf.dim[1]),
+					                              (uint32_t)cell_coord(P.z, gf.mn[2], gf.inv_cell, gf.dim[2]));
+			}
 		}
 	}
 	if (!valid || heavy) return;
@@ -1466,7 +1488,7 @@ int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n)
 }
 
 int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int npts, int count, float radius,
-                     float* d_rgb)
+                     float* d_rgb, bool coherent)
 {
 	if (npts <= 0) return RT_HIP_OK;
 	GridDesc gd;
@@ -1500,10 +1522,37 @@ int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, in
 		RT_HIP_CHECK(hipGetLastError());
 	}
 	RT_CHECK(rt_begin_trace_timing(ctx));
+	// tuning.gather_sort: the queue of the wave kernels sorted by the points' positions (Morton order of their fine-grid cells), so
+	// that neighbours in the queue are neighbours in space whatever order the caller's points come in: the pairs of the first pass
+	// (tuning.gather_pair) form, and the XCD-aware walk of the queue reads each part of the map from one L2.  The results are
+	// written by point index and do not depend on the queue's order.  1: unless the caller says its points are ordered already
+	// (level 0 of a frame: 8 x 8 tiles); 2: always.
+	// (1: not for a few thousand points either -- the sort is a dozen launches and a host wait for the queue's length)
+	const bool sort_queue = ctx->num_photons > 0 && ctx->tuning.gather_fine &&
+	                        (ctx->tuning.gather_sort >= 2 || (ctx->tuning.gather_sort == 1 && !coherent && npts >= 16384));
+	GridDesc gfk = gd;
+	uint64_t* heavy_keys = nullptr;
+	if (sort_queue) {
+		for (int k = 0; k < 3; ++k) { gfk.mn[k] = ctx->photon_grid_min_f[k]; gfk.dim[k] = ctx->photon_grid_dim_f[k]; }
+		gfk.cell = ctx->photon_cell_f; gfk.inv_cell = 1.0f / ctx->photon_cell_f;
+		RT_CHECK(ctx->d_morton.reserve((size_t)npts * 8));
+		RT_CHECK(ctx->d_morton_tmp.reserve((size_t)npts * 8));
+		RT_CHECK(ctx->d_order_tmp.reserve((size_t)npts * 4));
+		heavy_keys = ctx->d_morton.as<uint64_t>();
+	}
 	hipLaunchKernelGGL(k_photon_gather, dim3(nblocks(npts, GBLOCK)), dim3(GBLOCK), 0, ctx->stream, gd,
 	                   ctx->d_cell_start.as<uint32_t>(), ctx->d_photons.as<float4>(), ctx->d_photon_sorted.as<float4>(),
-	                   ctx->num_photons, d_pos, d_nrm, npts, count, radius, gc, d_rgb, heavy, heavy_queue, heavy_count);
+	                   ctx->num_photons, d_pos, d_nrm, npts, count, radius, gc, d_rgb, heavy, heavy_queue, heavy_count, gfk, heavy_keys);
 	RT_HIP_CHECK(hipGetLastError());
+	if (sort_queue) {
+		int nheavy = 0;
+		RT_HIP_CHECK(hipMemcpyAsync(&nheavy, heavy_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+		RT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		int maxdim = std::max(gfk.dim[0], std::max(gfk.dim[1], gfk.dim[2])), bits = 1;
+		while ((1 << bits) < maxdim) ++bits;
+		RT_CHECK(rt_radix_sort_pairs64(ctx, heavy_keys, ctx->d_morton_tmp.as<uint64_t>(), (uint32_t*)heavy_queue, ctx->d_order_tmp.as<uint32_t>(),
+		                               nheavy, 3 * bits));
+	}
 	if (ctx->num_photons > 0) {
 		// one wave per queued point, grid-stride over a queue whose length only the device knows
 		// a multiple of 8 * chunk blocks, so that the XCD-aware renumbering is a bijection

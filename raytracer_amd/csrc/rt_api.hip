@@ -101,6 +101,7 @@ void rt_default_tuning(rt_hip_tuning* t)
 	t->shadow_prefix_min_rays = env_int("RT_HIP_SHADOW_PREFIX_MIN_RAYS", -1);
 	t->frame_streams = env_int("RT_HIP_FRAME_STREAMS", 1);
 	t->gather_pair = env_int("RT_HIP_GATHER_PAIR", 100);
+	t->gather_sort = env_int("RT_HIP_GATHER_SORT", 1);
 	t->max_bvh_depth = 95;
 	t->refit_max_growth = 2.0f;
 	if (const char* e = getenv("RT_HIP_REFIT_GROWTH")) t->refit_max_growth = (float)atof(e);
@@ -127,6 +128,7 @@ void rt_clamp_tuning(rt_hip_ctx* ctx)
 	t.shadow_prefix_steps = std::min(1024, std::max(1, t.shadow_prefix_steps));
 	t.frame_streams = std::min(RT_MAX_PENDING, std::max(1, t.frame_streams));
 	t.gather_pair = std::min(100000, std::max(0, t.gather_pair));
+	t.gather_sort = std::min(2, std::max(0, t.gather_sort));
 	if (!(t.refit_max_growth >= 0.0f)) t.refit_max_growth = 0.0f;
 }
 

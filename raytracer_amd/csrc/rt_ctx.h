@@ -323,7 +323,7 @@ int rt_photon_emit(rt_hip_ctx* ctx, int per_light, int64_t first, int64_t count,
                    int64_t* out_stored);
 int rt_photon_build_grid(rt_hip_ctx* ctx, const float* d_photons, int64_t n);
 int rt_photon_gather(rt_hip_ctx* ctx, const float* d_pos, const float* d_nrm, int npts, int count, float radius,
-                     float* d_rgb);
+                     float* d_rgb, bool coherent = false);  // coherent: consecutive points are neighbours in space already
 int rt_photon_lookup(rt_hip_ctx* ctx, const float* d_pos, int npts, float radius, float* d_rgb);
 int rt_photon_unpermute(rt_hip_ctx* ctx, float* d_out);  // the installed set in photon-index order, num_photons x 9 floats
 

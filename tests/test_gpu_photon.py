@@ -127,6 +127,36 @@ def test_gather_first_pass_two_points_at_once(oracle_cls, count, radius):
         np.testing.assert_array_equal(got[ok], outs[0, 0][ok], err_msg=str(key))
 
 
+def test_gather_queue_sorted_by_position(oracle_cls):
+    """tuning.gather_sort: the wave kernels' queue in Morton order of the points' fine-grid cells.  The points are handed
+    over in random order (no two neighbours adjacent); unsorted, sorted, and sorted with every pair formed (which the sort
+    makes possible): the same bits, and the oracle's values -- a result is written by point index and a point's count,
+    max_dist2 and selection do not depend on who its neighbours in the queue are."""
+    import raytracer_amd as rt
+    sc = scenes.cornell()
+    orc = oracle_cls(sc)
+    ph = orc.photon_generate(8000, geometry=0, rng=1, seed=3)
+    nr, po = orc.software_gbuffer(64, 48)
+    pos, nrm, _ = orc.gbuffer_select(nr, po)
+    perm = np.random.RandomState(5).permutation(pos.shape[0])
+    pos, nrm = np.ascontiguousarray(pos[perm]), np.ascontiguousarray(nrm[perm])
+    orc.photon_set(ph)
+    exp = orc.radiance_estimate(pos, nrm, 100, 1.0)
+    ok = ~np.isnan(exp)
+    outs = {}
+    for sort, pair, heavy in ((0, 100, 0), (1, 100, 0), (2, 100, 0), (2, 0, 0), (2, 800, 0), (0, 100, 32), (1, 100, 32)):
+        g = rt.RtHip(sc, semantics="array", photon_radius=1.0, tuning=dict(gather_sort=sort, gather_pair=pair, gather_medium=0, gather_heavy=heavy))
+        assert g.tuning()["gather_sort"] == sort
+        g.photon_set(ph)
+        outs[sort, pair, heavy] = g.radiance_estimate(pos, nrm, 100, 1.0)
+        g.close()
+    for key, got in outs.items():
+        np.testing.assert_array_equal(np.isnan(exp), np.isnan(got), err_msg=str(key))
+        np.testing.assert_allclose(got[ok], exp[ok], rtol=2e-5, atol=1e-9, err_msg=str(key))
+        # (the lane-per-point kernel of the light points sums in another order than the wave kernels: compare like with like)
+        np.testing.assert_array_equal(got[ok], outs[0, 100, key[2]][ok], err_msg=str(key))
+
+
 @pytest.mark.parametrize("medium", [4096, 0], ids=["medium-default", "shell-walk-forced"])
 @pytest.mark.parametrize("heavy", [0, 4000000000], ids=["all-wave", "all-lane"])
 def test_gather_ties_at_the_kth_distance(oracle_cls, heavy, medium):
