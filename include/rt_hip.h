@@ -176,7 +176,8 @@ typedef struct rt_hip_tuning {
 	int gather_sort;          /* 1    RT_HIP_GATHER_SORT: the wave-per-point gather's queue sorted by the points' positions (Morton order of their
 	                           *      fine-grid cells) before the wave kernels: neighbours in the queue are then neighbours in space whatever order
 	                           *      the caller's points come in (pairs form, each part of the map is read through one XCD's L2).  1: except for
-	                           *      level 0 of a frame (8 x 8 tiles already); 2: always; 0: never.  Results do not depend on it. */
+	                           *      level 0 of a frame (8 x 8 tiles already), fewer than 16 k points or a map of fewer than 2 M photons (where
+	                           *      the sort costs more than it saves); 2: always; 0: never.  Results do not depend on it. */
 } rt_hip_tuning;
 
 /* Kernel-time accounting for bench.py.  Times are only filled when config.profile != 0 (hipEvent
