@@ -872,6 +872,7 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 	const int per_round = pairs ? 2 : 1;
 	const int nrounds = (nheavy + per_round - 1) / per_round;
 	for (int round = (int)xcd_block_index(xcd_chunk) * nw + wv; round < nrounds; round += gridDim.x * nw) {
+		bool coarse_known = false;   // the pair's cube on the coarse grid holds at most `medium` photons: so does each point's
 		if (pairs && 2 * round + 1 < nheavy) {
 			const int hq = 2 * round;
 			const int ia = __builtin_amdgcn_readfirstlane(heavy_queue[hq]), ib = __builtin_amdgcn_readfirstlane(heavy_queue[hq + 1]);
@@ -903,6 +904,43 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 					}
 				}
 				both = wave_sum_u(pop) > medium;
+				coarse_known = !both;
+			}
+			if (__builtin_amdgcn_readfirstlane(coarse_known ? 1 : 0)) {
+				// a sparse pair: everything within radius + en of the midpoint read once from the coarse grid, tested against both points
+				int nca_l = 0, ncb_l = 0;
+				uint32_t mxa_u = 0u, mxb_u = 0u;
+				const v2f PX = {A.x, B.x}, PY = {A.y, B.y}, PZ = {A.z, B.z};
+				const float rho = radius + en;
+				const int y0 = cell_coord(C.y - rho * 1.0001f, gdc.mn[1], gdc.inv_cell, gdc.dim[1]), y1 = cell_coord(C.y + rho * 1.0001f, gdc.mn[1], gdc.inv_cell, gdc.dim[1]);
+				const int z0 = cell_coord(C.z - rho * 1.0001f, gdc.mn[2], gdc.inv_cell, gdc.dim[2]), z1 = cell_coord(C.z + rho * 1.0001f, gdc.mn[2], gdc.inv_cell, gdc.dim[2]);
+				const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+				for (int rbase = 0; rbase < nrows; rbase += 64) {
+					const int row = rbase + lane;
+					uint32_t s0 = 0, s1 = 0;
+					if (row < nrows) {
+						const int zr = row / ny, y = y0 + (row - zr * ny), z = z0 + zr;
+						int x0, x1;
+						if (row_chord(gdc, C, rho * 1.0001f + 1e-30f, y, z, x0, x1)) {
+							const uint32_t rb = (uint32_t)((z * gdc.dim[1] + y) * gdc.dim[0]);
+							s0 = cell_start_c[rb + x0]; s1 = cell_start_c[rb + x1 + 1];
+						}
+					}
+					wave_visit_runs<true>(mark, pos_c, s0, s1, [&](const float4 q, uint32_t, bool act) {
+						const v2f qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+						const v2f dx = qx - PX, dy = qy - PY, dz = qz - PZ;
+						const v2f l2 = dx * dx + (dy * dy + dz * dz);   // dot3's order
+						const bool ina = act && l2.x < r2, inb = act && l2.y < r2;
+						nca_l += ina ? 1 : 0;
+						ncb_l += inb ? 1 : 0;
+						mxa_u = max(mxa_u, ina ? __float_as_uint(l2.x) : 0u);
+						mxb_u = max(mxb_u, inb ? __float_as_uint(l2.y) : 0u);
+					});
+				}
+				const int nca = wave_sum_i(nca_l), ncb = wave_sum_i(ncb_l);
+				const float mxa = wave_max_f(__uint_as_float(mxa_u)), mxb = wave_max_f(__uint_as_float(mxb_u));
+				if (lane == 0) { p1[hq] = make_float2(__int_as_float(nca), mxa); p1[hq + 1] = make_float2(__int_as_float(ncb), mxb); }
+				continue;
 			}
 			if (__builtin_amdgcn_readfirstlane(both ? 1 : 0)) {
 				int common_l = 0, nca_l = 0, ncb_l = 0;
@@ -949,8 +987,8 @@ void k_photon_gather_wave(GridDesc gd, const uint32_t* __restrict__ cell_start,
 			// A point with few photons around it pays for the fine grid's rows (17 x 17 of them, two calls of the run
 			// visitor per 64) and gains nothing from the counted interiors: if its cube on the COARSE grid (5 x 5 rows)
 			// holds at most `medium` photons, all of them are read from there in one go.
-			bool coarse_pass = false;
-			if (SHELL && PHASE == 1 && medium > 0u) {
+			bool coarse_pass = coarse_known;
+			if (SHELL && PHASE == 1 && medium > 0u && !coarse_known) {
 				const float rho = radius * 1.0001f + 1e-30f;
 				const int y0 = cell_coord(P.y - rho, gdc.mn[1], gdc.inv_cell, gdc.dim[1]), y1 = cell_coord(P.y + rho, gdc.mn[1], gdc.inv_cell, gdc.dim[1]);
 				const int z0 = cell_coord(P.z - rho, gdc.mn[2], gdc.inv_cell, gdc.dim[2]), z1 = cell_coord(P.z + rho, gdc.mn[2], gdc.inv_cell, gdc.dim[2]);
