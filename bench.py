@@ -639,11 +639,12 @@ def build_roofline(args, g, st, gb_p, gb_n, W, H, rank, world, tiles, strong):
             if k in counters:
                 roof[k] = counters[k]
     roof["counters_source"] = counters_note
-    roof.setdefault("bound_note", "per the counters the tightest resource is the vector-memory return path (td_busy_frac: each 16 B/lane load occupies the CU's "
-                                  "L1 data return for 16 cycles whatever the cache hit rate, and a node visit is two of them per wave, shared by the CU's four "
-                                  "SIMDs), then the waits of each wave's chain of dependent fetches (wait_any_frac); the vector ALU issues valu_issue_frac of the "
-                                  "slots it has at 2 cycles per wave64 instruction (rounds 1-2 quoted twice that: 4 cycles, the rate of a wave alone), at two "
-                                  "thirds of the lanes active; HBM carries a few percent of its peak")
+    roof.setdefault("bound_note", "a launch is as long as its waves' chains of dependent node fetches (wait_any_frac): the busiest unit is the vector-memory return "
+                                  "path (td_busy_frac: each 16 B/lane load occupies the CU's L1 data return for 16 cycles whatever the cache hit rate, a node visit "
+                                  "is two of them per wave, shared by the CU's four SIMDs), but halving the bytes per ray (two rays per lane, one fetch for both) "
+                                  "lengthened the launch by a quarter -- profiles/r3_variants/k_shadow.md 9; the vector ALU issues valu_issue_frac of the slots it "
+                                  "has at 2 cycles per wave64 instruction (rounds 1-2 quoted twice that: 4 cycles, the rate of a wave alone), at two thirds of "
+                                  "the lanes active; HBM carries a few percent of its peak")
     return roof
 
 
